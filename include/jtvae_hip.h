@@ -1,0 +1,181 @@
+/*
+ * jtvae_hip.h - C ABI of libjtvae_hip.so: the JT-VAE encoder message-passing
+ * path (MPN, JTNNEncoder/GraphGRU, JTMPN) as hand-written HIP kernels for
+ * MI355X (gfx950).
+ *
+ * The reference has no FFI: its encoder is Python calling stock ATen ops.  Each
+ * entry point below replaces the group of ATen calls named in its comment
+ * (file:line under the reference tree), so that a Python (ctypes), C or C++
+ * host can drive the path with plain device pointers.
+ *
+ * Conventions
+ *  - every pointer is DEVICE memory unless the parameter is documented "host";
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *    every call only enqueues work, none synchronises or allocates;
+ *  - return value: 0 = ok, negative = argument rejected before any launch
+ *    (JTVAE_E_*), positive = hipError_t from the launch;
+ *  - "row buffers" hold one feature row per graph element, fp32, row-major with
+ *    a leading dimension `ld` (floats).  The vectorised kernels need
+ *    ld % 4 == 0 and a 16-byte aligned base; columns [H, ld) are padding, which
+ *    every kernel here writes as zero and never lets leak into columns < H;
+ *  - graph adjacency is CSR: rowptr[n_rows+1], col[nnz], int32, built once per
+ *    batch from the reference's padded tables (agraph/bgraph/node_graph/
+ *    mess_graph) with the padding zeros dropped.  Dropping them is exact because
+ *    row 0 of every gathered buffer is the all-zero padding row in the
+ *    reference's layout (fast_jtnn/mpn.py:112-114, fast_jtnn/jtnn_enc.py:108-109,
+ *    fast_jtnn/jtmpn.py:83,95).
+ */
+#ifndef JTVAE_HIP_H
+#define JTVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JTVAE_ABI_VERSION 1
+
+#define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
+#define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
+#define JTVAE_E_ALIGN (-3)    /* ld or base address not 16-B aligned */
+#define JTVAE_E_RANGE (-4)    /* enum / mode out of range            */
+#define JTVAE_E_WORKSPACE (-5)/* workspace too small                 */
+
+/* activation codes for jtvae_gemm_nt */
+#define JTVAE_ACT_NONE 0
+#define JTVAE_ACT_RELU 1
+#define JTVAE_ACT_SIGMOID 2
+#define JTVAE_ACT_TANH 3
+
+/* epilogue modes for jtvae_gemm_nt */
+#define JTVAE_EPI_PLAIN 0     /* C = act(acc + bias + add)                                   */
+#define JTVAE_EPI_GRU_BLEND 1 /* p = tanh(acc+add); C = p; out2 = (1-z)*s + z*p (row 0 -> 0) */
+#define JTVAE_EPI_MUL_ACC 2   /* C = acc (+add); out2 += C * aux0                            */
+
+typedef struct jtvae_epilogue {
+  const float* bias;      /* [N] added to every row, or NULL                               */
+  const float* add;       /* addend rows, or NULL; may alias C (in-place accumulate)       */
+  int32_t ld_add;
+  const int32_t* add_idx; /* NULL: addend row = m; else addend row = add_idx[m] (table)    */
+  int32_t act;            /* JTVAE_ACT_*  (PLAIN mode only)                                */
+  float* pre_out;         /* PLAIN: optional copy of the pre-activation value, or NULL     */
+  int32_t ld_pre;
+  int32_t mode;           /* JTVAE_EPI_*                                                   */
+  const float* aux0;      /* GRU_BLEND: z rows;  MUL_ACC: multiplier rows                  */
+  const float* aux1;      /* GRU_BLEND: s rows                                             */
+  float* out2;            /* GRU_BLEND: new h;   MUL_ACC: accumulator rows (+=)            */
+  int32_t ld_aux;         /* leading dimension of aux0, aux1, out2                         */
+} jtvae_epilogue_t;
+
+int jtvae_abi_version(void);
+const char* jtvae_error_string(int code);
+
+/* ---- dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) ------------- */
+
+/* C[M,N] = epilogue(A[M,K] . W[N,K]^T).  Replaces every nn.Linear call on the path:
+ * fast_jtnn/mpn.py:87,93,99; fast_jtnn/jtnn_enc.py:33,115,117-118,124;
+ * fast_jtnn/jtmpn.py:89,96,103 (the torch.cat in front of W_o/W_z/W_h/outputNN is replaced
+ * by splitting the weight and chaining two calls through `add`).  A, W may have any ld and
+ * alignment (unaligned operands take a scalar-load path); C, add, aux need no alignment. */
+int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
+                  int32_t M, int32_t N, int32_t K, const jtvae_epilogue_t* epi, void* stream);
+
+/* dW[N,K] (+)= X[M,N]^T . Y[M,K]  - the weight gradient of C = Y.W^T given X = dC, reduced
+ * over M in fixed order (split-M slabs + ordered slab sum: bitwise reproducible, no atomics).
+ * Replaces autograd's addmm backward for every Linear on the path.
+ * workspace: at least jtvae_gemm_tn_workspace_bytes(M,N,K) bytes of device memory. */
+size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
+int jtvae_gemm_tn(const float* X, int32_t ldx, const float* Y, int32_t ldy, float* dW, int32_t lddw,
+                  int32_t M, int32_t N, int32_t K, int32_t accumulate, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* out[c] (+)= sum_m X[m,c] for c < N (bias gradients), fixed summation order.
+ * workspace: jtvae_colsum_workspace_bytes(M,N). */
+size_t jtvae_colsum_workspace_bytes(int32_t M, int32_t N);
+int jtvae_colsum(const float* X, int32_t ldx, float* out, int32_t M, int32_t N, int32_t accumulate,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* dst[c,r] = src[r,c] for r < rows, c < cols (weight transposes for the dgrad GEMMs). */
+int jtvae_transpose(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows,
+                    int32_t cols, void* stream);
+
+/* dst[r, 0:cols] = src[r, 0:cols]; dst columns [cols, ld_dst) = 0.  Any alignment.  Moves rows
+ * between torch's dense [rows, H] tensors and the padded row buffers. */
+int jtvae_copy_rows(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows,
+                    int32_t cols, void* stream);
+
+/* ---- neighbour gather-sum --------------------------------------------------------------- */
+
+/* out[i] = sum_{e in [rowptr[i], rowptr[i+1])} src(col[e])        for i < n_rows
+ *   src(j) = src0[j]            if j <  n_src0
+ *          = src1[j - n_src0]   otherwise          (src1 == NULL: single source)
+ *   then, in this order:  if relu_mask:  out[i] *= (relu_mask[i] > 0)
+ *                         if accumulate: out[i] += previous out[i]
+ *                         if acc2:       acc2[i] += out[i]
+ * Replaces index_select_ND(...).sum(dim=1) (fast_jtnn/nnutils.py:13-18 with mpn.py:91-92,
+ * 96-97; jtnn_enc.py:31-32; jtmpn.py:93-95, 99-101 - the two-source form stands in for the
+ * torch.cat([tree_message, graph_message]) copy) and, with the transposed CSR, its autograd
+ * backward (index_select backward = scatter-add) fused with the ReLU mask of mpn.py:94.
+ * All row buffers share `ld`. */
+int jtvae_csr_gather_sum(float* out, const float* src0, int32_t n_src0, const float* src1,
+                         const int32_t* rowptr, const int32_t* col, int32_t n_rows, int32_t H,
+                         int32_t ld, const float* relu_mask, int32_t accumulate, float* acc2,
+                         void* stream);
+
+/* out[m] = sum_{t < n_slabs} X[t*slab_stride + m*ld ...]  (sum of per-iteration gradients). */
+int jtvae_slab_sum(float* out, const float* X, int32_t n_slabs, size_t slab_stride, int32_t n_rows,
+                   int32_t H, int32_t ld, void* stream);
+
+/* Per-segment mean readout: out[b] = (1/len_b) * sum rows[start_b : start_b+len_b]
+ * (fast_jtnn/mpn.py:103-107, fast_jtnn/jtmpn.py:105-110).  seg = int32 [n_seg,2] (start,len). */
+int jtvae_segment_mean(float* out, const float* rows, const int32_t* seg, int32_t n_seg, int32_t H,
+                       int32_t ld, void* stream);
+
+/* Backward of the readout fused with the ReLU in front of it (mpn.py:99):
+ * drows[a] = dout[seg_of[a]] / len(seg_of[a]) * (act[a] > 0). */
+int jtvae_segment_mean_bwd(float* drows, const float* dout, const float* act, const int32_t* seg,
+                           const int32_t* seg_of, int32_t n_rows, int32_t H, int32_t ld, void* stream);
+
+/* ---- GraphGRU (fast_jtnn/jtnn_enc.py:107-128) ------------------------------------------- */
+
+/* First iteration, where h == 0: z = sigmoid(Pz[wid]), p = tanh(Ph[wid]), h1 = z*p, row 0 -> 0.
+ * Pz/Ph are per-word (or per-node) tables of W_z[:, :H].x + b_z and W_h[:, :H].x + b_h. */
+int jtvae_gru_iter0(const float* Pz, const float* Ph, const int32_t* wid, float* z, float* p,
+                    float* h1, int32_t n_mess, int32_t H, int32_t ld, void* stream);
+
+/* One pass over the incoming messages of every message m (jtnn_enc.py:112-113, 117-122):
+ *   s[m] = sum_e h[j_e]
+ *   g[m] = sum_e sigmoid(Pr[wid[m]] + Uh[j_e]) * h[j_e]        Uh = U_r h + b, once per message
+ *   t[m] = sum_e r_e (1 - r_e) h[j_e]                         (t may be NULL: inference)
+ * The [NM,K,H] tensors h_nei, r, gated_h of the reference are never materialised. */
+int jtvae_gru_gate_gather(const float* h, const float* Uh, const float* Pr, const int32_t* wid,
+                          const int32_t* rowptr, const int32_t* col, float* s, float* g, float* t,
+                          int32_t n_mess, int32_t H, int32_t ld, void* stream);
+
+/* Backward of the blend h' = ((1-z) s + z p) * mask (jtnn_enc.py:115,124-126):
+ *   dzpre = dh (p - s) z (1-z);  dppre = dh z (1-p^2);  ds = dh (1-z);  row 0 -> 0. */
+int jtvae_gru_bwd_pointwise(const float* dh, const float* z, const float* p, const float* s,
+                            float* dzpre, float* dppre, float* ds, int32_t n_mess, int32_t H,
+                            int32_t ld, void* stream);
+
+/* Backward of jtvae_gru_gate_gather with respect to h and Uh, over the TRANSPOSED graph
+ * (trowptr/tcol: for message j, the messages m that read it), r recomputed:
+ *   dUh[j]   = h[j] * sum_e dg[m_e] r_e (1 - r_e)
+ *   dhdir[j] = sum_e ( ds[m_e] + dg[m_e] r_e )              r_e = sigmoid(Pr[wid[m_e]] + Uh[j]) */
+int jtvae_gru_bwd_gather(const float* h, const float* Uh, const float* Pr, const int32_t* wid,
+                         const float* dg, const float* ds, const int32_t* trowptr,
+                         const int32_t* tcol, float* dUh, float* dhdir, int32_t n_mess, int32_t H,
+                         int32_t ld, void* stream);
+
+/* ---- bilinear assembly score (fast_jtnn/jtnn_vae.py:112-114) ---------------------------- */
+
+/* score[c] = < q[owner[c]], cand[c] >  for c < n_cand (q = A_assm z_mol rows). */
+int jtvae_row_dot(float* score, const float* q, const int32_t* owner, const float* cand,
+                  int32_t n_cand, int32_t H, int32_t ld, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JTVAE_HIP_H */

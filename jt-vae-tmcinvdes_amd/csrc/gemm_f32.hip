@@ -1,0 +1,475 @@
+// Dense contractions of the encoder path on the CDNA4 fp32 matrix cores.
+//
+// v_mfma_f32_32x32x2_f32 is an exact-fp32 fma chain (no reduced-precision fast
+// path exists on gfx950), which is what the 1e-4 parity bound over 20 recurrent
+// GRU iterations needs.  Two kernels:
+//
+//   gemm_nt : C[M,N] = epilogue(A[M,K] . W[N,K]^T)        forward Linear, and dgrad
+//                                                         with a transposed weight copy
+//   gemm_tn : dW[N,K] = X[M,N]^T . Y[M,K]                 weight gradients, reduction over
+//                                                         the (huge) row dimension, split
+//                                                         into slabs summed in fixed order
+//
+// N = K = 450 on the hot calls, M = 4e4..9e5.  Tiles are cut for that: the NT block
+// is 128 rows x 160 columns (3 column blocks cover 480 >= 450: 6 % padding waste,
+// against 14 % for 128/256-wide tiles), one wave owns 32 rows x 160 columns = five
+// 32x32 accumulators.
+#include "jtvae_common.h"
+#include "../../include/jtvae_hip.h"
+
+using namespace jtvae;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int NT_BM = 128;
+constexpr int NT_BN = 160;
+constexpr int NT_BK = 32;
+constexpr int NT_LDS = 36;  // floats per LDS row: 32 + 4 -> ds_read_b128 of 16 rows hits 16 distinct 16-B slots
+constexpr int NT_NT = NT_BN / 32;  // accumulators per wave
+
+// blocks that share an XCD (ids equal mod 8) get consecutive tiles, so the column
+// blocks of one row block read their A rows through one L2
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  int q = n >> 3, r = n & 7;
+  int x = id & 7;
+  int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (id >> 3);
+}
+
+struct NtArgs {
+  const float* A;
+  const float* W;
+  float* C;
+  int lda, ldw, ldc;
+  int M, N, K;
+  int n_tiles_n;
+  int n_blocks;
+  jtvae_epilogue_t e;
+};
+
+template <bool VEC>
+__device__ __forceinline__ float4 load4(const float* base, int ld, int row, int row_end, int k, int K) {
+  float4 v = f4zero();
+  if (row < row_end && k < K) {
+    const float* p = base + (size_t)row * ld + k;
+    if (VEC) {
+      v = *reinterpret_cast<const float4*>(p);
+      if (k + 3 >= K) {
+        if (k + 1 >= K) v.y = 0.f;
+        if (k + 2 >= K) v.z = 0.f;
+        v.w = 0.f;
+      }
+    } else {
+      v.x = p[0];
+      if (k + 1 < K) v.y = p[1];
+      if (k + 2 < K) v.z = p[2];
+      if (k + 3 < K) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case JTVAE_ACT_RELU: return v > 0.f ? v : 0.f;
+    case JTVAE_ACT_SIGMOID: return sigmoidf_fast(v);
+    case JTVAE_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[NT_BM * NT_LDS];
+  __shared__ __attribute__((aligned(16))) float Bs[NT_BN * NT_LDS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, a.n_blocks);
+  const int m0 = (tile / a.n_tiles_n) * NT_BM;
+  const int n0 = (tile % a.n_tiles_n) * NT_BN;
+
+  f32x16 acc[NT_NT];
+#pragma unroll
+  for (int t = 0; t < NT_NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int srow = tid >> 3;  // staging: 8 threads (8 x float4 = 32 floats) per tile row
+  const int sc4 = tid & 7;
+  float4 ra[4], rb[5];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = load4<VEC>(a.A, a.lda, m0 + srow + 32 * i, a.M, k0 + 4 * sc4, a.K);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) rb[i] = load4<VEC>(a.W, a.ldw, n0 + srow + 32 * i, a.N, k0 + 4 * sc4, a.K);
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[(srow + 32 * i) * NT_LDS + 4 * sc4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * NT_LDS + 4 * sc4]) = rb[i];
+  };
+
+  const int nk = (a.K + NT_BK - 1) / NT_BK;
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+
+  // operand fragment addresses: lane l supplies row (l & 31); its half (l >> 5) picks which
+  // four of the eight k values of a step group it feeds.  The same k permutation is used
+  // for A and B, so each MFMA sums matching products.
+  const float* a_frag = &As[(wave * 32 + (lane & 31)) * NT_LDS + 4 * (lane >> 5)];
+  const float* b_frag = &Bs[(lane & 31) * NT_LDS + 4 * (lane >> 5)];
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles((kt + 1) * NT_BK);  // in flight during the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < NT_BK / 8; ++kk) {
+      float4 av = *reinterpret_cast<const float4*>(a_frag + 8 * kk);
+      float4 bv[NT_NT];
+#pragma unroll
+      for (int t = 0; t < NT_NT; ++t) bv[t] = *reinterpret_cast<const float4*>(b_frag + t * 32 * NT_LDS + 8 * kk);
+#pragma unroll
+      for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: accumulator register r of lane l is C[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31]
+  const jtvae_epilogue_t& e = a.e;
+  const int col_in_tile = lane & 31;
+#pragma unroll
+  for (int t = 0; t < NT_NT; ++t) {
+    const int n = n0 + 32 * t + col_in_tile;
+    const bool n_ok = n < a.N;
+    const float bias = (e.bias && n_ok) ? e.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= a.M) continue;
+      if (!n_ok) {
+        // padding columns of the outputs are defined as zero
+        if (n < a.ldc) a.C[(size_t)m * a.ldc + n] = 0.f;
+        if (e.pre_out && n < e.ld_pre) e.pre_out[(size_t)m * e.ld_pre + n] = 0.f;
+        if (e.mode == JTVAE_EPI_GRU_BLEND && n < e.ld_aux) e.out2[(size_t)m * e.ld_aux + n] = 0.f;
+        continue;
+      }
+      float v = acc[t][r] + bias;
+      if (e.add) {
+        const int ar = e.add_idx ? e.add_idx[m] : m;
+        v += e.add[(size_t)ar * e.ld_add + n];
+      }
+      if (e.mode == JTVAE_EPI_PLAIN) {
+        if (e.pre_out) e.pre_out[(size_t)m * e.ld_pre + n] = v;
+        a.C[(size_t)m * a.ldc + n] = act_apply(v, e.act);
+      } else if (e.mode == JTVAE_EPI_GRU_BLEND) {
+        const float p = tanhf(v);
+        const float z = e.aux0[(size_t)m * e.ld_aux + n];
+        const float s = e.aux1[(size_t)m * e.ld_aux + n];
+        a.C[(size_t)m * a.ldc + n] = p;
+        e.out2[(size_t)m * e.ld_aux + n] = (m == 0) ? 0.f : fmaf(z, p - s, s);  // (1-z)s + zp
+      } else {  // JTVAE_EPI_MUL_ACC
+        a.C[(size_t)m * a.ldc + n] = v;
+        const size_t o = (size_t)m * e.ld_aux + n;
+        e.out2[o] = fmaf(v, e.aux0[o], e.out2[o]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// gemm_tn: partial[s][n][k] = sum_{m in slab s} X[m][n] * Y[m][k]
+// Block tile 128 (n) x 96 (k); wave w owns n rows [32w, 32w+32) and three 32x32 accumulators.
+// Operand tiles sit in LDS row-major as loaded (m-major): for one MFMA step lane l needs
+// X[m = 2*step + (l>>5)][n = l&31], i.e. 32 consecutive floats per half-wave: conflict-free
+// ds_read_b32 with no transpose anywhere.
+constexpr int TN_BN = 128;
+constexpr int TN_BKK = 96;
+constexpr int TN_BM = 32;
+
+struct TnArgs {
+  const float* X;
+  const float* Y;
+  float* P;  // [splits][N][ldp]
+  int ldx, ldy, ldp;
+  int M, N, K;
+  int tiles_n, tiles_k, rows_per_split;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[TN_BM * TN_BN];
+  __shared__ __attribute__((aligned(16))) float Ys[TN_BM * TN_BKK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = a.tiles_n * a.tiles_k;
+  const int split = blockIdx.x / tiles;
+  const int tile = blockIdx.x % tiles;
+  const int n0 = (tile / a.tiles_k) * TN_BN;
+  const int k0 = (tile % a.tiles_k) * TN_BKK;
+  const int m_beg = split * a.rows_per_split;
+  const int m_end = min(a.M, m_beg + a.rows_per_split);
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float4 rx[4], ry[3];
+  auto load_tiles = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = tid + 256 * i;  // 32 rows x 32 float4
+      rx[i] = load4<VEC>(a.X, a.ldx, mb + (idx >> 5), m_end, n0 + 4 * (idx & 31), a.N);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int idx = tid + 256 * i;  // 32 rows x 24 float4
+      ry[i] = load4<VEC>(a.Y, a.ldy, mb + idx / 24, m_end, k0 + 4 * (idx % 24), a.K);
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = tid + 256 * i;
+      *reinterpret_cast<float4*>(&Xs[(idx >> 5) * TN_BN + 4 * (idx & 31)]) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      int idx = tid + 256 * i;
+      *reinterpret_cast<float4*>(&Ys[(idx / 24) * TN_BKK + 4 * (idx % 24)]) = ry[i];
+    }
+  };
+
+  if (m_beg < m_end) {
+    load_tiles(m_beg);
+    store_tiles();
+    __syncthreads();
+    const float* xf = &Xs[(lane >> 5) * TN_BN + wave * 32 + (lane & 31)];
+    const float* yf = &Ys[(lane >> 5) * TN_BKK + (lane & 31)];
+    for (int mb = m_beg; mb < m_end; mb += TN_BM) {
+      const bool more = mb + TN_BM < m_end;
+      if (more) load_tiles(mb + TN_BM);
+#pragma unroll
+      for (int st = 0; st < TN_BM / 2; ++st) {
+        float xv = xf[2 * st * TN_BN];
+        float y0 = yf[2 * st * TN_BKK];
+        float y1 = yf[2 * st * TN_BKK + 32];
+        float y2 = yf[2 * st * TN_BKK + 64];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, y0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, y1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, y2, acc[2], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        store_tiles();
+        __syncthreads();
+      }
+    }
+  }
+
+  float* P = a.P + (size_t)split * a.N * a.ldp;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int k = k0 + 32 * t + (lane & 31);
+    if (k >= a.K) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (n < a.N) P[(size_t)n * a.ldp + k] = acc[t][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ P, int splits, int N, int K,
+                                                          int ldp, float* __restrict__ dW, int lddw,
+                                                          int accumulate) {
+  long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (long)N * K) return;
+  int n = (int)(gid / K), k = (int)(gid - (long)n * K);
+  const float* p = P + (size_t)n * ldp + k;
+  const size_t stride = (size_t)N * ldp;
+  float acc = 0.f;
+  for (int s = 0; s < splits; ++s) acc += p[s * stride];
+  float* o = dW + (size_t)n * lddw + k;
+  *o = accumulate ? *o + acc : acc;
+}
+
+// column sums: stage 1 sums a block of rows per column, stage 2 adds the block partials in order
+constexpr int CS_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ldx, int M, int N,
+                                                             float* __restrict__ part) {
+  int c = blockIdx.x * 256 + threadIdx.x;
+  int r0 = blockIdx.y * CS_ROWS;
+  int r1 = min(M, r0 + CS_ROWS);
+  if (c >= N) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {
+    a0 += X[(size_t)(r + 0) * ldx + c];
+    a1 += X[(size_t)(r + 1) * ldx + c];
+    a2 += X[(size_t)(r + 2) * ldx + c];
+    a3 += X[(size_t)(r + 3) * ldx + c];
+  }
+  for (; r < r1; ++r) a0 += X[(size_t)r * ldx + c];
+  part[(size_t)blockIdx.y * N + c] = (a0 + a1) + (a2 + a3);
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblk, int N,
+                                                           float* __restrict__ out, int accumulate) {
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float acc = 0.f;
+  for (int b = 0; b < nblk; ++b) acc += part[(size_t)b * N + c];
+  out[c] = accumulate ? out[c] + acc : acc;
+}
+
+inline bool aligned16(const void* p, int ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ld & 3) == 0); }
+inline int launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+struct TnPlan {
+  int tiles_n, tiles_k, splits, rows_per_split, ldp;
+};
+inline TnPlan tn_plan(int M, int N, int K) {
+  TnPlan p;
+  p.tiles_n = (N + TN_BN - 1) / TN_BN;
+  p.tiles_k = (K + TN_BKK - 1) / TN_BKK;
+  int tiles = p.tiles_n * p.tiles_k;
+  int want = (M + 255) / 256;               // at least 256 rows per slab
+  int cap = (1024 + tiles - 1) / tiles;     // about four blocks per CU in total
+  int s = want < cap ? want : cap;
+  if (s < 1) s = 1;
+  int rows = (M + s - 1) / s;
+  rows = (rows + TN_BM - 1) / TN_BM * TN_BM;
+  if (rows < TN_BM) rows = TN_BM;
+  p.rows_per_split = rows;
+  p.splits = M > 0 ? (M + rows - 1) / rows : 1;
+  p.ldp = (K + 3) & ~3;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc, int32_t M,
+                  int32_t N, int32_t K, const jtvae_epilogue_t* epi, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldc < N) return JTVAE_E_SHAPE;
+  if (M == 0) return 0;
+  if (!A || !W || !C) return JTVAE_E_NULL;
+  NtArgs a;
+  a.A = A; a.W = W; a.C = C;
+  a.lda = lda; a.ldw = ldw; a.ldc = ldc;
+  a.M = M; a.N = N; a.K = K;
+  if (epi) {
+    a.e = *epi;
+  } else {
+    a.e = jtvae_epilogue_t();
+    a.e.bias = nullptr; a.e.add = nullptr; a.e.add_idx = nullptr; a.e.pre_out = nullptr;
+    a.e.aux0 = nullptr; a.e.aux1 = nullptr; a.e.out2 = nullptr;
+    a.e.ld_add = a.e.ld_pre = a.e.ld_aux = 0; a.e.act = 0; a.e.mode = 0;
+  }
+  const jtvae_epilogue_t& e = a.e;
+  if (e.mode < 0 || e.mode > JTVAE_EPI_MUL_ACC || e.act < 0 || e.act > JTVAE_ACT_TANH) return JTVAE_E_RANGE;
+  if (e.add && e.ld_add < N) return JTVAE_E_SHAPE;
+  if (e.pre_out && e.ld_pre < N) return JTVAE_E_SHAPE;
+  if (e.mode == JTVAE_EPI_GRU_BLEND && (!e.aux0 || !e.aux1 || !e.out2 || e.ld_aux < N)) return JTVAE_E_NULL;
+  if (e.mode == JTVAE_EPI_MUL_ACC && (!e.aux0 || !e.out2 || e.ld_aux < N)) return JTVAE_E_NULL;
+  int tiles_m = (M + NT_BM - 1) / NT_BM;
+  a.n_tiles_n = (N + NT_BN - 1) / NT_BN;
+  a.n_blocks = tiles_m * a.n_tiles_n;
+  const bool vec = aligned16(A, lda) && aligned16(W, ldw);
+  hipStream_t s = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(a.n_blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(a.n_blocks), dim3(256), 0, s, a);
+  return launch_status();
+}
+
+size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
+  if (M < 0 || N <= 0 || K <= 0) return 0;
+  TnPlan p = tn_plan(M, N, K);
+  return (size_t)p.splits * N * p.ldp * sizeof(float);
+}
+
+int jtvae_gemm_tn(const float* X, int32_t ldx, const float* Y, int32_t ldy, float* dW, int32_t lddw, int32_t M,
+                  int32_t N, int32_t K, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+  if (M < 0 || N <= 0 || K <= 0 || ldx < N || ldy < K || lddw < K) return JTVAE_E_SHAPE;
+  if (!X || !Y || !dW || !workspace) return JTVAE_E_NULL;
+  TnPlan p = tn_plan(M, N, K);
+  if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float)) return JTVAE_E_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return JTVAE_E_ALIGN;
+  TnArgs a;
+  a.X = X; a.Y = Y; a.P = (float*)workspace;
+  a.ldx = ldx; a.ldy = ldy; a.ldp = p.ldp;
+  a.M = M; a.N = N; a.K = K;
+  a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.rows_per_split = p.rows_per_split;
+  hipStream_t s = (hipStream_t)stream;
+  int blocks = p.tiles_n * p.tiles_k * p.splits;
+  if (aligned16(X, ldx) && aligned16(Y, ldy))
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+  long total = (long)N * K;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.P, p.splits, N,
+                     K, p.ldp, dW, lddw, accumulate);
+  return launch_status();
+}
+
+size_t jtvae_colsum_workspace_bytes(int32_t M, int32_t N) {
+  if (M < 0 || N <= 0) return 0;
+  size_t nblk = (size_t)(M + CS_ROWS - 1) / CS_ROWS;
+  if (nblk < 1) nblk = 1;
+  return nblk * N * sizeof(float);
+}
+
+int jtvae_colsum(const float* X, int32_t ldx, float* out, int32_t M, int32_t N, int32_t accumulate,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+  if (M < 0 || N <= 0 || ldx < N) return JTVAE_E_SHAPE;
+  if (!X || !out || !workspace) return JTVAE_E_NULL;
+  if (workspace_bytes < jtvae_colsum_workspace_bytes(M, N)) return JTVAE_E_WORKSPACE;
+  int nblk = (M + CS_ROWS - 1) / CS_ROWS;
+  hipStream_t s = (hipStream_t)stream;
+  if (nblk > 0)
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nblk), dim3(256), 0, s, X, ldx, M, N,
+                       (float*)workspace);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, nblk, N,
+                     out, accumulate);
+  return launch_status();
+}
+
+int jtvae_abi_version(void) { return JTVAE_ABI_VERSION; }
+
+const char* jtvae_error_string(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case JTVAE_E_NULL: return "required pointer is NULL";
+    case JTVAE_E_SHAPE: return "negative or inconsistent sizes";
+    case JTVAE_E_ALIGN: return "row buffer not 16-byte aligned (base address or leading dimension)";
+    case JTVAE_E_RANGE: return "mode or enum out of range";
+    case JTVAE_E_WORKSPACE: return "workspace too small";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+}  // extern "C"

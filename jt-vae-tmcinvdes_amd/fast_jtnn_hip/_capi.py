@@ -1,0 +1,190 @@
+"""ctypes binding of libjtvae_hip.so (declared in include/jtvae_hip.h).
+
+There is no fallback: if the library is missing or a symbol is absent the import
+fails, and every call raises on a non-zero return code.  PyTorch is used only to
+own device memory and to name the stream; tensors cross the boundary as raw
+device pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
+ABI_VERSION = 1
+
+
+class Epilogue(C.Structure):
+    _fields_ = [
+        ("bias", C.c_void_p),
+        ("add", C.c_void_p),
+        ("ld_add", C.c_int32),
+        ("add_idx", C.c_void_p),
+        ("act", C.c_int32),
+        ("pre_out", C.c_void_p),
+        ("ld_pre", C.c_int32),
+        ("mode", C.c_int32),
+        ("aux0", C.c_void_p),
+        ("aux1", C.c_void_p),
+        ("out2", C.c_void_p),
+        ("ld_aux", C.c_int32),
+    ]
+
+
+_i32, _vp, _sz = C.c_int32, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); must list every function of include/jtvae_hip.h
+SIGNATURES = {
+    "jtvae_abi_version": (C.c_int, []),
+    "jtvae_error_string": (C.c_char_p, [C.c_int]),
+    "jtvae_gemm_nt": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
+    "jtvae_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "jtvae_gemm_tn": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "jtvae_colsum_workspace_bytes": (_sz, [_i32, _i32]),
+    "jtvae_colsum": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "jtvae_transpose": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_csr_gather_sum": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "jtvae_slab_sum": (C.c_int, [_vp, _vp, _i32, _sz, _i32, _i32, _i32, _vp]),
+    "jtvae_segment_mean": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_segment_mean_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_gru_iter0": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_gru_gate_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_gru_bwd_pointwise": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_gru_bwd_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_row_dot": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libjtvae_hip.so is not built (expected at %s); run `make -C jt-vae-tmcinvdes_amd/csrc` "
+            "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.jtvae_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError("libjtvae_hip.so ABI %d, host code expects %d" % (got, ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+class JtvaeError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise JtvaeError("%s failed: %s (code %d)" % (what, lib.jtvae_error_string(rc).decode(), rc))
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t, offset_elems: int = 0):
+    """Device pointer of a tensor (None -> NULL), optionally offset by elements."""
+    if t is None:
+        return None
+    return t.data_ptr() + offset_elems * t.element_size()
+
+
+LD_ALIGN = 4
+
+
+def round_ld(h: int) -> int:
+    return (h + LD_ALIGN - 1) // LD_ALIGN * LD_ALIGN
+
+
+def rows(n: int, ld: int, device, zero: bool = False) -> torch.Tensor:
+    """A padded row buffer [n, ld] fp32."""
+    f = torch.zeros if zero else torch.empty
+    return f((max(n, 0), ld), dtype=torch.float32, device=device)
+
+
+# ---- thin call wrappers (sizes are taken from explicit arguments, never guessed) -----------
+
+
+def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0, add_idx=None,
+            act=ACT_NONE, pre_out=None, ld_pre=0, mode=EPI_PLAIN, aux0=None, aux1=None, out2=None,
+            ld_aux=0):
+    """All tensor arguments are raw device pointers (ints) or None."""
+    e = Epilogue(bias, add, ld_add, add_idx, act, pre_out, ld_pre, mode, aux0, aux1, out2, ld_aux)
+    check(lib.jtvae_gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()), "jtvae_gemm_nt")
+
+
+def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device):
+    nbytes = lib.jtvae_gemm_tn_workspace_bytes(M, N, K)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    check(lib.jtvae_gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, int(accumulate), ws.data_ptr(), nbytes,
+                            stream_ptr()), "jtvae_gemm_tn")
+
+
+def colsum(X, ldx, out, M, N, accumulate, device):
+    nbytes = lib.jtvae_colsum_workspace_bytes(M, N)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    check(lib.jtvae_colsum(X, ldx, out, M, N, int(accumulate), ws.data_ptr(), nbytes, stream_ptr()),
+          "jtvae_colsum")
+
+
+def transpose(src, ld_src, dst, ld_dst, nrows, ncols):
+    check(lib.jtvae_transpose(src, ld_src, dst, ld_dst, nrows, ncols, stream_ptr()), "jtvae_transpose")
+
+
+def copy_rows(src, ld_src, dst, ld_dst, nrows, ncols):
+    check(lib.jtvae_copy_rows(src, ld_src, dst, ld_dst, nrows, ncols, stream_ptr()), "jtvae_copy_rows")
+
+
+def csr_gather_sum(out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask=None, accumulate=False,
+                   acc2=None):
+    check(lib.jtvae_csr_gather_sum(out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask,
+                                   int(accumulate), acc2, stream_ptr()), "jtvae_csr_gather_sum")
+
+
+def slab_sum(out, X, n_slabs, slab_stride, n_rows, H, ld):
+    check(lib.jtvae_slab_sum(out, X, n_slabs, slab_stride, n_rows, H, ld, stream_ptr()), "jtvae_slab_sum")
+
+
+def segment_mean(out, rows_, seg, n_seg, H, ld):
+    check(lib.jtvae_segment_mean(out, rows_, seg, n_seg, H, ld, stream_ptr()), "jtvae_segment_mean")
+
+
+def segment_mean_bwd(drows, dout, act, seg, seg_of, n_rows, H, ld):
+    check(lib.jtvae_segment_mean_bwd(drows, dout, act, seg, seg_of, n_rows, H, ld, stream_ptr()),
+          "jtvae_segment_mean_bwd")
+
+
+def gru_iter0(Pz, Ph, wid, z, p, h1, n_mess, H, ld):
+    check(lib.jtvae_gru_iter0(Pz, Ph, wid, z, p, h1, n_mess, H, ld, stream_ptr()), "jtvae_gru_iter0")
+
+
+def gru_gate_gather(h, Uh, Pr, wid, rowptr, col, s, g, t, n_mess, H, ld):
+    check(lib.jtvae_gru_gate_gather(h, Uh, Pr, wid, rowptr, col, s, g, t, n_mess, H, ld, stream_ptr()),
+          "jtvae_gru_gate_gather")
+
+
+def gru_bwd_pointwise(dh, z, p, s, dzpre, dppre, ds, n_mess, H, ld):
+    check(lib.jtvae_gru_bwd_pointwise(dh, z, p, s, dzpre, dppre, ds, n_mess, H, ld, stream_ptr()),
+          "jtvae_gru_bwd_pointwise")
+
+
+def gru_bwd_gather(h, Uh, Pr, wid, dg, ds, trowptr, tcol, dUh, dhdir, n_mess, H, ld):
+    check(lib.jtvae_gru_bwd_gather(h, Uh, Pr, wid, dg, ds, trowptr, tcol, dUh, dhdir, n_mess, H, ld,
+                                   stream_ptr()), "jtvae_gru_bwd_gather")
+
+
+def row_dot(score, q, owner, cand, n_cand, H, ld):
+    check(lib.jtvae_row_dot(score, q, owner, cand, n_cand, H, ld, stream_ptr()), "jtvae_row_dot")

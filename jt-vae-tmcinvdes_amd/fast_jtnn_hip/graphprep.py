@@ -1,0 +1,296 @@
+"""Per-batch index preparation: the reference's padded neighbour tables -> device CSR.
+
+The reference hands the encoder padded int64 tables (agraph/bgraph [N,6] or [N,15],
+node_graph/mess_graph [N,Kmax]) in which 0 means "no neighbour"
+(fast_jtnn/mpn.py:148-159, fast_jtnn/jtnn_enc.py:78-90, fast_jtnn/jtmpn.py:170-181).
+The kernels want, per batch and once for all 2 / 20 iterations:
+
+  * the same adjacency as int32 CSR without the padding slots (slot order kept,
+    so sums run in the reference's neighbour order),
+  * its transpose (who reads row j), which turns the backward scatter-add into a
+    second gather: no atomics, bitwise reproducible,
+  * small derived index vectors (word id per message, molecule of each atom ...).
+
+This is index bookkeeping in the same class as tensorize itself; it runs on the
+host with numpy, once per batch, and its result is cached on the holder tuple.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+@dataclass
+class DeviceCSR:
+    rowptr: torch.Tensor  # int32 [n_rows + 1]
+    col: torch.Tensor  # int32 [nnz]
+    n_rows: int
+    nnz: int
+
+
+def _to_np(t) -> np.ndarray:
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def padded_to_csr(table: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Rows of a zero-padded table -> (rowptr, col) keeping the slot order of the non-zeros."""
+    table = np.ascontiguousarray(table)
+    if table.ndim != 2:
+        raise ValueError("neighbour table must be 2-D, got shape %s" % (table.shape,))
+    nz = table != 0
+    counts = nz.sum(axis=1).astype(np.int64)
+    rowptr = np.zeros(table.shape[0] + 1, dtype=np.int64)
+    np.cumsum(counts, out=rowptr[1:])
+    col = table[nz]  # row-major order: row by row, slot by slot
+    return rowptr, col.astype(np.int64)
+
+
+def transpose_csr(rowptr: np.ndarray, col: np.ndarray, n_src: int) -> Tuple[np.ndarray, np.ndarray]:
+    """For every source row j the list of rows i that read it, ordered by (i, slot)."""
+    n_rows = rowptr.shape[0] - 1
+    counts = np.diff(rowptr)
+    row_of = np.repeat(np.arange(n_rows, dtype=np.int64), counts)
+    order = np.argsort(col, kind="stable")
+    tcol = row_of[order]
+    trowptr = np.zeros(n_src + 1, dtype=np.int64)
+    np.cumsum(np.bincount(col, minlength=n_src), out=trowptr[1:])
+    return trowptr, tcol
+
+
+def chunk_lists(rowptr: np.ndarray, chunk: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Split every list into pieces of at most ``chunk`` entries.
+
+    Returns (piece_rowptr over the same col array, key_rowptr: pieces of each key).
+    Long lists (all messages that share a word id) then sum in parallel, piece by
+    piece, and the pieces of a key are added in order.
+    """
+    counts = np.diff(rowptr)
+    n_pieces = np.maximum(1, -(-counts // chunk))  # an empty list keeps one empty piece
+    key_rowptr = np.zeros(rowptr.shape[0], dtype=np.int64)
+    np.cumsum(n_pieces, out=key_rowptr[1:])
+    total = int(key_rowptr[-1])
+    key_of_piece = np.repeat(np.arange(counts.shape[0], dtype=np.int64), n_pieces)
+    idx_in_key = np.arange(total, dtype=np.int64) - key_rowptr[key_of_piece]
+    start = rowptr[key_of_piece] + idx_in_key * chunk
+    end = np.minimum(start + chunk, rowptr[key_of_piece + 1])
+    piece_rowptr = np.empty(total + 1, dtype=np.int64)
+    piece_rowptr[:-1] = start
+    piece_rowptr[-1] = rowptr[-1]
+    # pieces are laid out in key order and lists are contiguous, so start[i+1] == end[i]
+    assert total == 0 or np.array_equal(piece_rowptr[1:], end)
+    return piece_rowptr, key_rowptr
+
+
+def check_range(col: np.ndarray, n_src: int, what: str) -> None:
+    if col.size and (int(col.min()) < 0 or int(col.max()) >= n_src):
+        raise IndexError("%s: neighbour index out of range [0, %d): min %d max %d"
+                         % (what, n_src, int(col.min()), int(col.max())))
+
+
+def _dev_i32(a: np.ndarray, device) -> torch.Tensor:
+    if a.size and int(a.max()) >= 2 ** 31:
+        raise OverflowError("index exceeds int32")
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+
+def upload_csr(rowptr: np.ndarray, col: np.ndarray, device) -> DeviceCSR:
+    col_t = _dev_i32(col if col.size else np.zeros(1, dtype=np.int64), device)
+    return DeviceCSR(_dev_i32(rowptr, device), col_t, int(rowptr.shape[0] - 1), int(col.shape[0]))
+
+
+def pad_cols(x: np.ndarray, mult: int = 4) -> np.ndarray:
+    """Zero-pad the feature columns to a multiple of ``mult`` (16-byte rows for float32)."""
+    n, f = x.shape
+    fp = (f + mult - 1) // mult * mult
+    out = np.zeros((n, fp), dtype=np.float32)
+    out[:, :f] = x
+    return out
+
+
+def scope_arrays(scope: Sequence[Tuple[int, int]], n_rows: int) -> Tuple[np.ndarray, np.ndarray]:
+    seg = np.asarray(scope, dtype=np.int64).reshape(-1, 2)
+    if seg.size and (seg[:, 0].min() < 0 or (seg[:, 0] + seg[:, 1]).max() > n_rows or seg[:, 1].min() < 0):
+        raise IndexError("scope exceeds the %d rows it indexes" % n_rows)
+    lens = seg[:, 1] if seg.size else np.zeros(0, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]) if seg.size else lens
+    if seg.size and np.array_equal(seg[:, 0], starts) and int(lens.sum()) == n_rows:
+        seg_of = np.repeat(np.arange(seg.shape[0], dtype=np.int64), lens)  # the tensorizers' layout
+    else:
+        seg_of = np.full(n_rows, -1, dtype=np.int64)  # rows outside every segment get no gradient
+        for b in range(seg.shape[0]):  # any other disjoint layout
+            seg_of[seg[b, 0]:seg[b, 0] + seg[b, 1]] = b
+    return seg, seg_of
+
+
+@dataclass
+class GraphMPNPrep:
+    """Device-side form of an (fatoms, fbonds, agraph, bgraph, scope) holder.
+
+    Source rows of both gathers live in one index space: ``n_tree`` tree-message
+    rows first (0 for the plain MPN), then the ``n_bonds`` bond-message rows.
+    """
+
+    fatoms: torch.Tensor  # [NA, round4(atom_fdim)]
+    fbonds: torch.Tensor  # [NB, round4(atom_fdim + bond_fdim)]
+    atom_fdim: int
+    bond_in_fdim: int
+    n_atoms: int
+    n_bonds: int
+    n_tree: int
+    bcsr: DeviceCSR
+    bcsr_t: DeviceCSR  # n_tree + n_bonds rows
+    acsr: DeviceCSR
+    acsr_t: DeviceCSR
+    seg: torch.Tensor  # int32 [B, 2]
+    seg_of: torch.Tensor  # int32 [NA]
+    n_seg: int
+
+
+def prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
+    fatoms, fbonds, agraph, bgraph, scope = holder
+    fa, fb = _to_np(fatoms).astype(np.float32), _to_np(fbonds).astype(np.float32)
+    ag, bg = _to_np(agraph), _to_np(bgraph)
+    na, nb = fa.shape[0], fb.shape[0]
+    if ag.shape[0] != na or bg.shape[0] != nb:
+        raise ValueError("agraph/bgraph row counts (%d, %d) do not match fatoms/fbonds (%d, %d)"
+                         % (ag.shape[0], bg.shape[0], na, nb))
+    n_src = n_tree + nb
+    b_rp, b_col = padded_to_csr(bg)
+    a_rp, a_col = padded_to_csr(ag)
+    check_range(b_col, n_src, "bgraph")
+    check_range(a_col, n_src, "agraph")
+    bt_rp, bt_col = transpose_csr(b_rp, b_col, n_src)
+    at_rp, at_col = transpose_csr(a_rp, a_col, n_src)
+    seg, seg_of = scope_arrays(scope, na)
+    return GraphMPNPrep(
+        fatoms=torch.from_numpy(pad_cols(fa)).to(device),
+        fbonds=torch.from_numpy(pad_cols(fb)).to(device),
+        atom_fdim=fa.shape[1], bond_in_fdim=fb.shape[1],
+        n_atoms=na, n_bonds=nb, n_tree=n_tree,
+        bcsr=upload_csr(b_rp, b_col, device), bcsr_t=upload_csr(bt_rp, bt_col, device),
+        acsr=upload_csr(a_rp, a_col, device), acsr_t=upload_csr(at_rp, at_col, device),
+        seg=_dev_i32(seg.reshape(-1), device).view(-1, 2) if seg.size else torch.zeros((0, 2), dtype=torch.int32, device=device),
+        seg_of=_dev_i32(seg_of, device) if na else torch.zeros(1, dtype=torch.int32, device=device),
+        n_seg=int(seg.shape[0]),
+    )
+
+
+@dataclass
+class TreePrep:
+    """Device-side form of an (fnode, fmess, node_graph, mess_graph, scope) holder."""
+
+    n_nodes: int
+    n_mess: int
+    n_trees: int
+    n_words: int  # distinct word ids in the batch
+    words: torch.Tensor  # int32 [n_words] word id of each table row
+    word_csr: DeviceCSR  # identity-shaped CSR: row u gathers embedding row words[u]
+    word_csr_t: DeviceCSR  # over the full vocabulary: which table row (if any) a word maps to
+    wid_m: torch.Tensor  # int32 [NM] table row of the source node of each message
+    wid_root: torch.Tensor  # int32 [B]
+    mcsr: DeviceCSR
+    mcsr_t: DeviceCSR
+    rcsr: DeviceCSR  # B rows: incoming messages of each root node
+    rcsr_t: DeviceCSR  # NM rows: the roots a message flows into
+    ident: DeviceCSR  # B-row identity
+    key_m_pieces: DeviceCSR  # messages grouped by table row, cut in pieces
+    key_m: DeviceCSR  # pieces of each table row
+    key_r_pieces: DeviceCSR
+    key_r: DeviceCSR
+    vocab_size: int
+
+
+KEY_CHUNK = 32
+
+
+def _key_lists(keys: np.ndarray, n_keys: int, device):
+    """Inverted index key -> members, as two-level CSR (pieces of <= KEY_CHUNK)."""
+    order = np.argsort(keys, kind="stable")
+    rp = np.zeros(n_keys + 1, dtype=np.int64)
+    np.cumsum(np.bincount(keys, minlength=n_keys), out=rp[1:])
+    piece_rp, key_rp = chunk_lists(rp, KEY_CHUNK)
+    pieces = upload_csr(piece_rp, order.astype(np.int64), device)
+    key_csr = upload_csr(key_rp, np.arange(piece_rp.shape[0] - 1, dtype=np.int64), device)
+    return pieces, key_csr
+
+
+def prepare_tree(holder, device, vocab_size: int) -> TreePrep:
+    fnode, fmess, node_graph, mess_graph, scope = holder
+    fn, fm = _to_np(fnode).astype(np.int64), _to_np(fmess).astype(np.int64)
+    ng, mg = _to_np(node_graph), _to_np(mess_graph)
+    nn_, nm = fn.shape[0], fm.shape[0]
+    if ng.shape[0] != nn_ or mg.shape[0] != nm:
+        raise ValueError("node_graph/mess_graph row counts do not match fnode/fmess")
+    if nn_ == 0 or nm == 0:
+        raise ValueError("empty tree batch")
+    check_range(fn, vocab_size, "fnode")
+    check_range(fm, nn_, "fmess")
+    m_rp, m_col = padded_to_csr(mg)
+    check_range(m_col, nm, "mess_graph")
+    mt_rp, mt_col = transpose_csr(m_rp, m_col, nm)
+    roots = np.asarray([st for st, _ in scope], dtype=np.int64)
+    check_range(roots, nn_, "scope")
+    r_rp, r_col = padded_to_csr(ng[roots])
+    check_range(r_col, nm, "node_graph")
+    rt_rp, rt_col = transpose_csr(r_rp, r_col, nm)
+    nb = roots.shape[0]
+
+    words, inv = np.unique(fn, return_inverse=True)
+    nw = words.shape[0]
+    wid_node = inv.astype(np.int64)
+    wid_m = wid_node[fm]
+    wid_root = wid_node[roots]
+    w_rp = np.arange(nw + 1, dtype=np.int64)
+    wt_rp, wt_col = transpose_csr(w_rp, words, vocab_size)
+
+    km_p, km = _key_lists(wid_m, nw, device)
+    kr_p, kr = _key_lists(wid_root, nw, device)
+    ar = np.arange(nb + 1, dtype=np.int64)
+    return TreePrep(
+        n_nodes=nn_, n_mess=nm, n_trees=nb, n_words=nw,
+        words=_dev_i32(words, device),
+        word_csr=upload_csr(w_rp, words, device), word_csr_t=upload_csr(wt_rp, wt_col, device),
+        wid_m=_dev_i32(wid_m, device), wid_root=_dev_i32(wid_root, device),
+        mcsr=upload_csr(m_rp, m_col, device), mcsr_t=upload_csr(mt_rp, mt_col, device),
+        rcsr=upload_csr(r_rp, r_col, device), rcsr_t=upload_csr(rt_rp, rt_col, device),
+        ident=upload_csr(ar, ar[:-1], device),
+        key_m_pieces=km_p, key_m=km, key_r_pieces=kr_p, key_r=kr,
+        vocab_size=vocab_size,
+    )
+
+
+# ---- caching on the holder object --------------------------------------------------------
+
+_CACHE_ATTR = "_jtvae_prep"
+
+
+class PreparedHolder(tuple):
+    """A holder tuple that remembers its device-side form.
+
+    ``tuple`` subclass, so ``model(*holder)`` and unpacking work as with the
+    reference's plain tuples.
+    """
+
+    def __new__(cls, items):
+        self = super().__new__(cls, items)
+        self._prep = {}
+        return self
+
+
+def cached_prep(key_tensor, tag, build):
+    """Cache by identity of the (CPU) index tensor the caller passes in every step."""
+    cache = getattr(key_tensor, _CACHE_ATTR, None)
+    if cache is None:
+        cache = {}
+        try:
+            setattr(key_tensor, _CACHE_ATTR, cache)
+        except AttributeError:
+            return build()
+    if tag not in cache:
+        cache[tag] = build()
+    return cache[tag]

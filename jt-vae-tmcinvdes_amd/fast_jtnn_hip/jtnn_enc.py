@@ -1,0 +1,350 @@
+"""Junction-tree encoder (tree message passing GRU) on the HIP kernels.
+
+Drop-in for ``fast_jtnn.jtnn_enc.JTNNEncoder`` / ``GraphGRU``
+(fast_jtnn/jtnn_enc.py:8-128): same constructors, same parameter names
+(``embedding.weight``, ``outputNN.0.{weight,bias}``, ``GRU.W_z.{weight,bias}``,
+``GRU.W_r.weight``, ``GRU.U_r.{weight,bias}``, ``GRU.W_h.{weight,bias}``), same
+``forward(fnode, fmess, node_graph, mess_graph, scope) -> (tree_vecs, messages)``.
+
+What is computed differently from the reference's op sequence (same mathematics):
+
+* x = E[word of the message's source node] never changes over the 20 iterations, so
+  ``W_z[:, :H] x + b_z``, ``W_r x``, ``W_h[:, :H] x + b_h`` and ``outputNN[:, :H] x + b``
+  are computed once per *distinct word of the batch* (a few hundred rows) and looked
+  up by the kernels; the reference recomputes ``W_r x`` on every message in every
+  iteration (jtnn_enc.py:117).
+* ``U_r`` is applied to each message once (a [NM,H]x[H,H] GEMM) and gathered, instead
+  of to every (message, neighbour) pair (jtnn_enc.py:118: [NM*K, H] x [H, H]).
+* gather, reset gate, both neighbour sums are one kernel; the update gate and the
+  blend are epilogues of the two remaining GEMMs.
+* only the root node of each tree needs ``outputNN`` (jtnn_enc.py:36-41 keeps
+  ``node_vecs[st]`` only), so the output stage runs on B rows.
+* backward is explicit; every per-iteration tensor it needs is kept in HBM
+  (7 row buffers per iteration) instead of autograd's [NM, K, H] saves.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _capi as K
+from . import graphprep
+from .mpn import _pack_weight, _pack_weight_t, as_row_buffer, dense_view
+
+
+class _TreeGRU:
+    """Shared forward/backward body of GraphGRU, on padded row buffers.
+
+    Tables Pz, Pr, Ph are [n_words, ld]; wid maps a message to its table row.
+    """
+
+    @staticmethod
+    def forward(h0_is_zero, depth, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur, bu, Whh, train):
+        T = depth
+        st = {}
+        if train:
+            hs = torch.empty((T + 1, NM, ld), dtype=torch.float32, device=dev)
+            hs[0].zero_()
+            zs = torch.empty((T, NM, ld), dtype=torch.float32, device=dev)
+            ps = torch.empty_like(zs)
+            ss = torch.empty_like(zs)
+            gs = torch.empty_like(zs)
+            ts = torch.empty_like(zs)
+            us = torch.empty_like(zs)
+            ss[0].zero_()
+            st = dict(hs=hs, zs=zs, ps=ps, ss=ss, gs=gs, ts=ts, us=us)
+        else:
+            hs = torch.empty((2, NM, ld), dtype=torch.float32, device=dev)
+            zs = torch.empty((1, NM, ld), dtype=torch.float32, device=dev)
+            ps, ss, gs, us = (torch.empty_like(zs) for _ in range(4))
+            ts = None
+        assert h0_is_zero
+        if T == 0:
+            hs[0].zero_()
+            return hs[0], st
+        wid_p = wid.data_ptr()
+        # iteration 0: every neighbour sum is zero
+        h_next = hs[1]
+        K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, zs[0].data_ptr(), ps[0].data_ptr(), h_next.data_ptr(),
+                    NM, H, ld)
+        for t in range(1, T):
+            i = t if train else 0
+            h = hs[t] if train else hs[t & 1]
+            h_next = hs[t + 1] if train else hs[(t + 1) & 1]
+            # Uh = U_r h + b
+            K.gemm_nt(h.data_ptr(), ld, Ur.data_ptr(), ld, us[i].data_ptr(), ld, NM, H, H, bias=bu.data_ptr())
+            K.gru_gate_gather(h.data_ptr(), us[i].data_ptr(), Pr.data_ptr(), wid_p, mcsr.rowptr.data_ptr(),
+                              mcsr.col.data_ptr(), ss[i].data_ptr(), gs[i].data_ptr(),
+                              ts[i].data_ptr() if train else None, NM, H, ld)
+            # z = sigmoid(W_z[:, H:] s + Pz[wid])
+            K.gemm_nt(ss[i].data_ptr(), ld, Wzh.data_ptr(), ld, zs[i].data_ptr(), ld, NM, H, H,
+                      add=Pz.data_ptr(), ld_add=ld, add_idx=wid_p, act=K.ACT_SIGMOID)
+            # p = tanh(W_h[:, H:] g + Ph[wid]);  h' = (1-z) s + z p, padding row kept zero
+            K.gemm_nt(gs[i].data_ptr(), ld, Whh.data_ptr(), ld, ps[i].data_ptr(), ld, NM, H, H,
+                      add=Ph.data_ptr(), ld_add=ld, add_idx=wid_p, mode=K.EPI_GRU_BLEND,
+                      aux0=zs[i].data_ptr(), aux1=ss[i].data_ptr(), out2=h_next.data_ptr(), ld_aux=ld)
+        return h_next, st
+
+    @staticmethod
+    def backward(dh, depth, NM, H, ld, dev, st, Pr, wid, mcsr_t, WzhT, WhhT, UrT):
+        """dh: gradient w.r.t. the final h (row buffer, modified in place).
+        Returns (dzpre[T], dppre[T], dUh[T], A_r) for the weight / table gradients."""
+        T = depth
+        hs, zs, ps, ss, gs, ts, us = (st[k] for k in ("hs", "zs", "ps", "ss", "gs", "ts", "us"))
+        dz = torch.empty((T, NM, ld), dtype=torch.float32, device=dev)
+        dp = torch.empty_like(dz)
+        du = torch.empty_like(dz)
+        a_r = torch.zeros((NM, ld), dtype=torch.float32, device=dev)
+        ds = K.rows(NM, ld, dev)
+        dg = K.rows(NM, ld, dev)
+        dhdir = K.rows(NM, ld, dev)
+        wid_p = wid.data_ptr()
+        for t in range(T - 1, 0, -1):
+            K.gru_bwd_pointwise(dh.data_ptr(), zs[t].data_ptr(), ps[t].data_ptr(), ss[t].data_ptr(),
+                                dz[t].data_ptr(), dp[t].data_ptr(), ds.data_ptr(), NM, H, ld)
+            # ds += dzpre W_z[:, H:]
+            K.gemm_nt(dz[t].data_ptr(), ld, WzhT.data_ptr(), ld, ds.data_ptr(), ld, NM, H, H,
+                      add=ds.data_ptr(), ld_add=ld)
+            # dg = dppre W_h[:, H:];  A_r += dg * t   (gradient reaching W_r x through the reset gate)
+            K.gemm_nt(dp[t].data_ptr(), ld, WhhT.data_ptr(), ld, dg.data_ptr(), ld, NM, H, H,
+                      mode=K.EPI_MUL_ACC, aux0=ts[t].data_ptr(), out2=a_r.data_ptr(), ld_aux=ld)
+            K.gru_bwd_gather(hs[t].data_ptr(), us[t].data_ptr(), Pr.data_ptr(), wid_p, dg.data_ptr(),
+                             ds.data_ptr(), mcsr_t.rowptr.data_ptr(), mcsr_t.col.data_ptr(),
+                             du[t].data_ptr(), dhdir.data_ptr(), NM, H, ld)
+            # dh_t = dUh U_r + direct part
+            K.gemm_nt(du[t].data_ptr(), ld, UrT.data_ptr(), ld, dh.data_ptr(), ld, NM, H, H,
+                      add=dhdir.data_ptr(), ld_add=ld)
+        if T >= 1:
+            K.gru_bwd_pointwise(dh.data_ptr(), zs[0].data_ptr(), ps[0].data_ptr(), ss[0].data_ptr(),
+                                dz[0].data_ptr(), dp[0].data_ptr(), ds.data_ptr(), NM, H, ld)
+        return dz, dp, du, a_r
+
+
+def _keyed_sum(src, pieces, key_csr, n_keys, H, ld, dev):
+    """out[k] = sum of src rows whose key is k (fixed order: pieces, then pieces of a key)."""
+    part = K.rows(pieces.n_rows, ld, dev)
+    K.csr_gather_sum(part.data_ptr(), src.data_ptr(), src.shape[0], None, pieces.rowptr.data_ptr(),
+                     pieces.col.data_ptr(), pieces.n_rows, H, ld)
+    out = K.rows(n_keys, ld, dev)
+    K.csr_gather_sum(out.data_ptr(), part.data_ptr(), pieces.n_rows, None, key_csr.rowptr.data_ptr(),
+                     key_csr.col.data_ptr(), n_keys, H, ld)
+    return out
+
+
+class _JTNNEncoderFunction(torch.autograd.Function):
+    """forward(E, Wout, bout, Wz, bz, Wr, Ur, bu, Wh, bh) -> (tree_vecs [B,H], messages [NM,H])"""
+
+    @staticmethod
+    def forward(ctx, E, Wout, bout, Wz, bz, Wr, Ur_w, bu, Wh, bh, prep, depth):
+        dev = E.device
+        H = Wr.shape[0]
+        ld = K.round_ld(H)
+        P = prep
+        NM, B, NW = P.n_mess, P.n_trees, P.n_words
+        train = any(ctx.needs_input_grad)
+        ctx.set_materialize_grads(False)  # an unused output (messages in encode_latent) costs nothing
+
+        # embedding rows of the words that occur in the batch            (jtnn_enc.py:27-28)
+        E_p = as_row_buffer(E, H, ld)
+        Eu = K.rows(NW, ld, dev)
+        K.csr_gather_sum(Eu.data_ptr(), E_p.data_ptr(), E.shape[0], None, P.word_csr.rowptr.data_ptr(),
+                         P.word_csr.col.data_ptr(), NW, H, ld)
+        Wzx, Wzh = _pack_weight(Wz, 0, H), _pack_weight(Wz, H, H)
+        Whx, Whh = _pack_weight(Wh, 0, H), _pack_weight(Wh, H, H)
+        Wox, Woh = _pack_weight(Wout, 0, H), _pack_weight(Wout, H, H)
+        Wr_p, Ur_p = _pack_weight(Wr, 0, H), _pack_weight(Ur_w, 0, H)
+        Pz, Pr, Ph, Po = (K.rows(NW, ld, dev) for _ in range(4))
+        K.gemm_nt(Eu.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NW, H, H, bias=bz.detach().data_ptr())
+        K.gemm_nt(Eu.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NW, H, H)
+        K.gemm_nt(Eu.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NW, H, H, bias=bh.detach().data_ptr())
+        K.gemm_nt(Eu.data_ptr(), ld, Wox.data_ptr(), ld, Po.data_ptr(), ld, NW, H, H, bias=bout.detach().data_ptr())
+
+        h, st = _TreeGRU.forward(True, depth, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p,
+                                 bu.detach(), Whh, train)
+
+        # output stage on the root nodes only                             (jtnn_enc.py:31-41)
+        nsum = K.rows(B, ld, dev)
+        K.csr_gather_sum(nsum.data_ptr(), h.data_ptr(), NM, None, P.rcsr.rowptr.data_ptr(),
+                         P.rcsr.col.data_ptr(), B, H, ld)
+        tv = K.rows(B, ld, dev)
+        K.gemm_nt(nsum.data_ptr(), ld, Woh.data_ptr(), ld, tv.data_ptr(), ld, B, H, H, add=Po.data_ptr(),
+                  ld_add=ld, add_idx=P.wid_root.data_ptr(), act=K.ACT_RELU)
+        if train:
+            ctx.prep, ctx.depth, ctx.H, ctx.ld = P, depth, H, ld
+            ctx.st = st
+            ctx.keep = (Eu, Pr, nsum, tv, Wout, Wz, Wr, Ur_w, Wh)
+            ctx.vocab = E.shape[0]
+        return dense_view(tv, H), dense_view(h, H)
+
+    @staticmethod
+    def backward(ctx, dtv, dmess):
+        P, depth, H, ld = ctx.prep, ctx.depth, ctx.H, ctx.ld
+        Eu, Pr, nsum, tv, Wout, Wz, Wr, Ur_w, Wh = ctx.keep
+        st = ctx.st
+        dev = Eu.device
+        NM, B, NW, V = P.n_mess, P.n_trees, P.n_words, ctx.vocab
+        T = depth
+
+        dWout = torch.empty((H, 2 * H), dtype=torch.float32, device=dev)
+        dWz = torch.empty((H, 2 * H), dtype=torch.float32, device=dev)
+        dWh = torch.empty((H, 2 * H), dtype=torch.float32, device=dev)
+        dWr = torch.empty((H, H), dtype=torch.float32, device=dev)
+        dUr = torch.empty((H, H), dtype=torch.float32, device=dev)
+        dbout, dbz, dbu, dbh = (torch.empty((H,), dtype=torch.float32, device=dev) for _ in range(4))
+
+        WohT = _pack_weight_t(Wout, H, H)
+        # root stage: relu mask, W_out[:, H:] gradient, back to the messages that feed a root
+        dpre_root = K.rows(B, ld, dev)
+        if dtv is None:
+            dpre_root.zero_()
+        else:
+            dtv_p = as_row_buffer(dtv, H, ld)
+            K.csr_gather_sum(dpre_root.data_ptr(), dtv_p.data_ptr(), B, None, P.ident.rowptr.data_ptr(),
+                             P.ident.col.data_ptr(), B, H, ld, relu_mask=tv.data_ptr())
+        K.gemm_tn(dpre_root.data_ptr(), ld, nsum.data_ptr(), ld, K.ptr(dWout, H), 2 * H, B, H, H, False, dev)
+        dnsum = K.rows(B, ld, dev)
+        K.gemm_nt(dpre_root.data_ptr(), ld, WohT.data_ptr(), ld, dnsum.data_ptr(), ld, B, H, H)
+        dh = K.rows(NM, ld, dev)
+        if dmess is not None:
+            K.copy_rows(dmess.data_ptr() if dmess.stride(1) == 1 else dmess.contiguous().data_ptr(),
+                        dmess.stride(0) if dmess.stride(1) == 1 else H, dh.data_ptr(), ld, NM, H)
+        K.csr_gather_sum(dh.data_ptr(), dnsum.data_ptr(), B, None, P.rcsr_t.rowptr.data_ptr(),
+                         P.rcsr_t.col.data_ptr(), NM, H, ld, accumulate=dmess is not None)
+
+        WzhT, WhhT, UrT = _pack_weight_t(Wz, H, H), _pack_weight_t(Wh, H, H), _pack_weight_t(Ur_w, 0, H)
+        dz, dp, du, a_r = _TreeGRU.backward(dh, T, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT, WhhT, UrT)
+
+        # weight gradients of the three per-iteration GEMMs, one contraction over all iterations
+        if T >= 2:
+            Mtot = (T - 1) * NM
+            K.gemm_tn(dz[1].data_ptr(), ld, st["ss"][1].data_ptr(), ld, K.ptr(dWz, H), 2 * H, Mtot, H, H, False, dev)
+            K.gemm_tn(dp[1].data_ptr(), ld, st["gs"][1].data_ptr(), ld, K.ptr(dWh, H), 2 * H, Mtot, H, H, False, dev)
+            K.gemm_tn(du[1].data_ptr(), ld, st["hs"][1].data_ptr(), ld, dUr.data_ptr(), H, Mtot, H, H, False, dev)
+            K.colsum(du[1].data_ptr(), ld, dbu.data_ptr(), Mtot, H, False, dev)
+        else:
+            dWz[:, H:].zero_()
+            dWh[:, H:].zero_()
+            dUr.zero_()
+            dbu.zero_()
+
+        # gradients of the per-word tables
+        dPo = _keyed_sum(dpre_root, P.key_r_pieces, P.key_r, NW, H, ld, dev)
+        if T >= 1:
+            a_z, a_h = K.rows(NM, ld, dev), K.rows(NM, ld, dev)
+            K.slab_sum(a_z.data_ptr(), dz.data_ptr(), T, NM * ld, NM, H, ld)
+            K.slab_sum(a_h.data_ptr(), dp.data_ptr(), T, NM * ld, NM, H, ld)
+            dPz = _keyed_sum(a_z, P.key_m_pieces, P.key_m, NW, H, ld, dev)
+            dPh = _keyed_sum(a_h, P.key_m_pieces, P.key_m, NW, H, ld, dev)
+            dPr = _keyed_sum(a_r, P.key_m_pieces, P.key_m, NW, H, ld, dev)
+        else:
+            dPz, dPh, dPr = (K.rows(NW, ld, dev, zero=True) for _ in range(3))
+        for dPt, dW, db in ((dPz, dWz, dbz), (dPh, dWh, dbh), (dPo, dWout, dbout)):
+            K.gemm_tn(dPt.data_ptr(), ld, Eu.data_ptr(), ld, dW.data_ptr(), 2 * H, NW, H, H, False, dev)
+            K.colsum(dPt.data_ptr(), ld, db.data_ptr(), NW, H, False, dev)
+        K.gemm_tn(dPr.data_ptr(), ld, Eu.data_ptr(), ld, dWr.data_ptr(), H, NW, H, H, False, dev)
+        # embedding gradient: dEu = sum_tables dP W[:, :H], scattered to the rows of the words used
+        dEu = K.rows(NW, ld, dev)
+        first = True
+        for dPt, W in ((dPz, Wz), (dPh, Wh), (dPo, Wout), (dPr, Wr)):
+            WT = _pack_weight_t(W, 0, H)
+            K.gemm_nt(dPt.data_ptr(), ld, WT.data_ptr(), ld, dEu.data_ptr(), ld, NW, H, H,
+                      add=None if first else dEu.data_ptr(), ld_add=ld)
+            first = False
+        dE_p = K.rows(V, ld, dev)
+        K.csr_gather_sum(dE_p.data_ptr(), dEu.data_ptr(), NW, None, P.word_csr_t.rowptr.data_ptr(),
+                         P.word_csr_t.col.data_ptr(), V, H, ld)
+        dE = torch.empty((V, H), dtype=torch.float32, device=dev)
+        K.copy_rows(dE_p.data_ptr(), ld, dE.data_ptr(), H, V, H)
+        return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None
+
+
+class GraphGRU(nn.Module):
+    """Parameter container with the reference's layout (fast_jtnn/jtnn_enc.py:95-105).
+
+    ``forward(h, x, mess_graph)`` keeps the reference signature for stand-alone use:
+    ``x`` are per-message input rows, ``h`` must be the zero start state.
+    """
+
+    def __init__(self, input_size, hidden_size, depth):
+        super(GraphGRU, self).__init__()
+        self.hidden_size = hidden_size
+        self.input_size = input_size
+        self.depth = depth
+        self.W_z = nn.Linear(input_size + hidden_size, hidden_size)
+        self.W_r = nn.Linear(input_size, hidden_size, bias=False)
+        self.U_r = nn.Linear(hidden_size, hidden_size)
+        self.W_h = nn.Linear(input_size + hidden_size, hidden_size)
+
+    def forward(self, h, x, mess_graph):
+        """Inference-only entry with explicit per-message inputs (no table sharing):
+        every message is its own table row."""
+        if self.input_size != self.hidden_size:
+            raise ValueError("GraphGRU kernels need input_size == hidden_size")
+        dev = self.W_r.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("fast_jtnn_hip.GraphGRU runs on an MI355X only; there is no CPU path")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("stand-alone GraphGRU.forward is inference-only; train through JTNNEncoder")
+        H = self.hidden_size
+        ld = K.round_ld(H)
+        mg = graphprep._to_np(mess_graph)
+        NM = mg.shape[0]
+        if tuple(h.shape) != (NM, H) or tuple(x.shape) != (NM, H):
+            raise ValueError("h and x must be [%d, %d]" % (NM, H))
+        rp, col = graphprep.padded_to_csr(mg)
+        graphprep.check_range(col, NM, "mess_graph")
+        mcsr = graphprep.upload_csr(rp, col, dev)
+        wid = torch.arange(NM, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev), torch.no_grad():
+            x_p = as_row_buffer(x.to(dev), H, ld)
+            Wz, Wh = self.W_z.weight, self.W_h.weight
+            Wzx, Wzh = _pack_weight(Wz, 0, H), _pack_weight(Wz, H, H)
+            Whx, Whh = _pack_weight(Wh, 0, H), _pack_weight(Wh, H, H)
+            Wr_p, Ur_p = _pack_weight(self.W_r.weight, 0, H), _pack_weight(self.U_r.weight, 0, H)
+            Pz, Pr, Ph = (K.rows(NM, ld, dev) for _ in range(3))
+            K.gemm_nt(x_p.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NM, H, H,
+                      bias=self.W_z.bias.data_ptr())
+            K.gemm_nt(x_p.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NM, H, H)
+            K.gemm_nt(x_p.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NM, H, H,
+                      bias=self.W_h.bias.data_ptr())
+            out, _ = _TreeGRU.forward(True, self.depth, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur_p,
+                                      self.U_r.bias.detach(), Whh, False)
+        return dense_view(out, H)
+
+
+class JTNNEncoder(nn.Module):
+    def __init__(self, hidden_size, depth, embedding):
+        super(JTNNEncoder, self).__init__()
+        self.hidden_size = hidden_size
+        self.depth = depth
+        self.embedding = embedding
+        self.outputNN = nn.Sequential(nn.Linear(2 * hidden_size, hidden_size), nn.ReLU())
+        self.GRU = GraphGRU(hidden_size, hidden_size, depth=depth)
+
+    def forward(self, fnode, fmess, node_graph, mess_graph, scope):
+        dev = self.GRU.W_r.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("fast_jtnn_hip.JTNNEncoder runs on an MI355X only (module is on %s); there is "
+                               "no CPU path" % dev)
+        V = self.embedding.weight.shape[0]
+        key = mess_graph if isinstance(mess_graph, torch.Tensor) else None
+        build = lambda: graphprep.prepare_tree((fnode, fmess, node_graph, mess_graph, scope), dev, V)  # noqa: E731
+        prep = build() if key is None else graphprep.cached_prep(key, ("tree", str(dev), V), build)
+        g = self.GRU
+        lin = self.outputNN[0]
+        with torch.cuda.device(dev):
+            return _JTNNEncoderFunction.apply(self.embedding.weight, lin.weight, lin.bias, g.W_z.weight,
+                                              g.W_z.bias, g.W_r.weight, g.U_r.weight, g.U_r.bias,
+                                              g.W_h.weight, g.W_h.bias, prep, self.depth)
+
+    @staticmethod
+    def tensorize(tree_batch):
+        from .tensorize import jtenc_tensorize
+
+        return jtenc_tensorize(tree_batch)
+
+    @staticmethod
+    def tensorize_nodes(node_batch, scope):
+        from .tensorize import jtenc_tensorize_nodes
+
+        return jtenc_tensorize_nodes(node_batch, scope)

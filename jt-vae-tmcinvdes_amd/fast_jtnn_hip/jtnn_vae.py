@@ -1,0 +1,182 @@
+"""Model wrappers that own the three encoder modules under the reference's
+attribute names, so a reference state dict loads unchanged.
+
+Mirrors the encoder-side surface of ``fast_jtnn.jtnn_vae.JTNNVAE``
+(fast_jtnn/jtnn_vae.py:18-138) and ``fast_jtnn.jtprop_vae.JTpropVAE``
+(fast_jtnn/jtprop_vae.py:27-136, 361-476): ``encode``, ``encode_latent``,
+``rsample``, ``assm`` and ``forward``.  The sequential tree decoder is not part
+of this package: pass any module with the reference decoder's call signature as
+``decoder`` (for example the reference's own ``JTNNDecoder`` running in
+PyTorch-ROCm); without one, ``forward`` returns the encoder-side terms only.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .jtmpn import JTMPN
+from .jtnn_enc import JTNNEncoder
+from .mpn import MPN
+
+
+def segment_cross_entropy(scores: torch.Tensor, seg_len: torch.Tensor, label_pos: torch.Tensor):
+    """Sum over segments of CrossEntropy(scores[segment], label) and the number of segments
+    whose label scores highest - the loop of fast_jtnn/jtnn_vae.py:116-135 without one launch
+    and one host sync per tree node.
+
+    scores [NC]; seg_len [S] candidates per node (consecutive); label_pos [S] global index of the label.
+    """
+    S = seg_len.shape[0]
+    seg_id = torch.repeat_interleave(torch.arange(S, device=scores.device), seg_len)
+    smax = torch.full((S,), float("-inf"), device=scores.device, dtype=scores.dtype)
+    smax = smax.scatter_reduce(0, seg_id, scores.detach(), reduce="amax")
+    ex = torch.exp(scores - smax[seg_id])
+    denom = torch.zeros(S, device=scores.device, dtype=scores.dtype).index_add(0, seg_id, ex)
+    lab = scores[label_pos]
+    loss = (torch.log(denom) + smax - lab).sum()
+    acc = (lab.detach() >= smax).sum()
+    return loss, acc
+
+
+class JTNNVAE(nn.Module):
+    def __init__(self, vocab, hidden_size, latent_size, depthT, depthG, decoder=None):
+        super(JTNNVAE, self).__init__()
+        self.vocab = vocab
+        self.hidden_size = hidden_size
+        self.latent_size = latent_size = latent_size // 2  # tree and graph halves (jtnn_vae.py:23-25)
+
+        self.jtnn = JTNNEncoder(hidden_size, depthT, nn.Embedding(vocab.size(), hidden_size))
+        if decoder is not None:
+            self.decoder = decoder
+        self.jtmpn = JTMPN(hidden_size, depthG)
+        self.mpn = MPN(hidden_size, depthG)
+
+        self.A_assm = nn.Linear(latent_size, hidden_size, bias=False)
+        self.T_mean = nn.Linear(hidden_size, latent_size)
+        self.T_var = nn.Linear(hidden_size, latent_size)
+        self.G_mean = nn.Linear(hidden_size, latent_size)
+        self.G_var = nn.Linear(hidden_size, latent_size)
+
+    def encode(self, jtenc_holder, mpn_holder):  # jtnn_vae.py:45-48
+        tree_vecs, tree_mess = self.jtnn(*jtenc_holder)
+        mol_vecs = self.mpn(*mpn_holder)
+        return tree_vecs, tree_mess, mol_vecs
+
+    def encode_latent(self, jtenc_holder, mpn_holder):  # jtnn_vae.py:56-65
+        tree_vecs, _ = self.jtnn(*jtenc_holder)
+        mol_vecs = self.mpn(*mpn_holder)
+        tree_mean = self.T_mean(tree_vecs)
+        mol_mean = self.G_mean(mol_vecs)
+        tree_var = -torch.abs(self.T_var(tree_vecs))
+        mol_var = -torch.abs(self.G_var(mol_vecs))
+        return torch.cat([tree_mean, mol_mean], dim=1), torch.cat([tree_var, mol_var], dim=1)
+
+    def encode_vectors(self, jtenc_holder, mpn_holder):
+        """[B, 2H] = cat(tree_vecs, mol_vecs): what bulk latent generation stores
+        (``encode_from_smiles``, jtnn_vae.py:50-54, after its RDKit front end)."""
+        tree_vecs, _, mol_vecs = self.encode(jtenc_holder, mpn_holder)
+        return torch.cat([tree_vecs, mol_vecs], dim=-1)
+
+    def rsample(self, z_vecs, W_mean, W_var, epsilon=None):  # jtnn_vae.py:67-78
+        batch_size = z_vecs.size(0)
+        z_mean = W_mean(z_vecs)
+        z_log_var = -torch.abs(W_var(z_vecs))
+        kl_loss = -0.5 * torch.sum(1.0 + z_log_var - z_mean * z_mean - torch.exp(z_log_var)) / batch_size
+        if epsilon is None:
+            epsilon = torch.randn_like(z_mean)
+        z_vecs = z_mean + torch.exp(z_log_var / 2) * epsilon
+        return z_vecs, kl_loss
+
+    def assm_scores(self, jtmpn_holder, x_mol_vecs, x_tree_mess):  # jtnn_vae.py:105-114
+        jtmpn_holder, batch_idx = jtmpn_holder
+        fatoms, fbonds, agraph, bgraph, scope = jtmpn_holder
+        batch_idx = batch_idx.to(x_mol_vecs.device)
+        cand_vecs = self.jtmpn(fatoms, fbonds, agraph, bgraph, scope, x_tree_mess)
+        q = self.A_assm(x_mol_vecs.index_select(0, batch_idx))
+        return (q * cand_vecs).sum(dim=1)
+
+    def assm(self, mol_batch, jtmpn_holder, x_mol_vecs, x_tree_mess):  # jtnn_vae.py:105-138
+        scores = self.assm_scores(jtmpn_holder, x_mol_vecs, x_tree_mess)
+        seg_len, label_pos, tot = [], [], 0
+        for mol_tree in mol_batch:
+            for node in mol_tree.nodes:
+                if len(node.cands) > 1 and not node.is_leaf:
+                    label_pos.append(tot + node.cands.index(node.label))
+                    seg_len.append(len(node.cands))
+                    tot += len(node.cands)
+        dev = scores.device
+        loss, acc = segment_cross_entropy(scores, torch.tensor(seg_len, device=dev),
+                                          torch.tensor(label_pos, device=dev))
+        return loss / len(mol_batch), acc.item() * 1.0 / len(seg_len)
+
+    def forward(self, x_batch, beta, epsilons=None):  # jtnn_vae.py:85-103
+        x_batch, x_jtenc_holder, x_mpn_holder, x_jtmpn_holder = x_batch
+        x_tree_vecs, x_tree_mess, x_mol_vecs = self.encode(x_jtenc_holder, x_mpn_holder)
+        e_t, e_g = epsilons if epsilons is not None else (None, None)
+        z_tree_vecs, tree_kl = self.rsample(x_tree_vecs, self.T_mean, self.T_var, e_t)
+        z_mol_vecs, mol_kl = self.rsample(x_mol_vecs, self.G_mean, self.G_var, e_g)
+        kl_div = tree_kl + mol_kl
+        if hasattr(self, "decoder"):
+            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs)
+        else:
+            word_loss = topo_loss = z_tree_vecs.sum() * 0.0
+            word_acc = topo_acc = 0.0
+        assm_loss, assm_acc = self.assm(x_batch, x_jtmpn_holder, z_mol_vecs, x_tree_mess)
+        return word_loss + topo_loss + assm_loss + beta * kl_div, kl_div.item(), word_acc, topo_acc, assm_acc
+
+
+class JTpropVAE(JTNNVAE):
+    """Conditional variant: adds the property regressor on the sampled latent
+    (fast_jtnn/jtprop_vae.py:62-66, 394-397)."""
+
+    def __init__(self, vocab, hidden_size, latent_size, depthT, depthG, train_mode=(), decoder=None):
+        super(JTpropVAE, self).__init__(vocab, hidden_size, latent_size, depthT, depthG, decoder=decoder)
+        self.propNN = nn.Sequential(nn.Linear(self.latent_size * 2, self.hidden_size), nn.Tanh(),
+                                    nn.Linear(self.hidden_size, 2))
+        self.train_mode = tuple(train_mode)
+        for term in self.train_mode:
+            if term == "denticity":
+                self.denticityNN = nn.Sequential(nn.Linear(self.latent_size * 2, self.hidden_size), nn.Sigmoid(),
+                                                 nn.Linear(self.hidden_size, 1))
+            elif term == "isomer":
+                self.isomerNN = nn.Sequential(nn.Linear(self.latent_size * 2, self.hidden_size), nn.Sigmoid(),
+                                              nn.Linear(self.hidden_size, 3))
+            else:
+                raise ValueError("train_mode is not a valid value")
+        self.prop_loss = nn.MSELoss()
+
+    def forward(self, x_batch, beta, epsilons=None):  # jtprop_vae.py:361-441
+        x_batch, x_prop_holder, x_jtenc_holder, x_mpn_holder, x_jtmpn_holder = x_batch
+        length_p = x_prop_holder.shape[1]
+        if length_p not in (2, 3, 4):
+            raise ValueError("The correct number of properties could not be unpacked")
+        x_tree_vecs, x_tree_mess, x_mol_vecs = self.encode(x_jtenc_holder, x_mpn_holder)
+        e_t, e_g = epsilons if epsilons is not None else (None, None)
+        z_tree_vecs, tree_kl = self.rsample(x_tree_vecs, self.T_mean, self.T_var, e_t)
+        z_mol_vecs, mol_kl = self.rsample(x_mol_vecs, self.G_mean, self.G_var, e_g)
+        kl_div = tree_kl + mol_kl
+        if hasattr(self, "decoder"):
+            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs)
+        else:
+            word_loss = topo_loss = z_tree_vecs.sum() * 0.0
+            word_acc = topo_acc = 0.0
+        assm_loss, assm_acc = self.assm(x_batch, x_jtmpn_holder, z_mol_vecs, x_tree_mess)
+        all_vec = torch.cat([z_tree_vecs, z_mol_vecs], dim=1)
+        dev = all_vec.device
+        prop_label = x_prop_holder[:, 0:2].to(dev).float()
+        prop_loss = self.prop_loss(self.propNN(all_vec).squeeze(), prop_label)
+        loss = word_loss + topo_loss + assm_loss + beta * kl_div + prop_loss
+        log_metrics = {"kl_div": kl_div.item(), "word_acc": word_acc * 100, "topo_acc": topo_acc * 100,
+                       "assm_acc": assm_acc * 100, "prop_loss": prop_loss.item() * 100}
+        for term in self.train_mode:
+            if term == "denticity":
+                lab = x_prop_holder[:, 2].to(dev).float()
+                dent_loss = nn.functional.binary_cross_entropy_with_logits(self.denticityNN(all_vec).squeeze(), lab)
+                loss = loss + dent_loss
+                log_metrics["dent_loss"] = dent_loss.item() * 100
+            elif term == "isomer":
+                lab = x_prop_holder[:, 3].to(dev).long()
+                isomer_loss = nn.functional.cross_entropy(self.isomerNN(all_vec).squeeze(), lab)
+                loss = loss + isomer_loss
+                log_metrics["isomer_loss"] = isomer_loss.item() * 100
+        return loss, log_metrics

@@ -1,0 +1,247 @@
+"""Molecular-graph message passing network on the HIP kernels.
+
+Drop-in for ``fast_jtnn.mpn.MPN`` (fast_jtnn/mpn.py:71-161): same constructor,
+same parameter names and shapes (``W_i.weight [H,51]``, ``W_h.weight [H,H]``,
+``W_o.weight [H,39+H]``, ``W_o.bias``), same ``forward(fatoms, fbonds, agraph,
+bgraph, scope) -> [B, H]``.
+
+The computation is restated for the device instead of translated:
+
+* ``index_select_ND(message, 0, bgraph).sum(1)`` becomes one CSR gather-sum kernel
+  (no [NB, 6, H] tensor);
+* ``relu(binput + W_h(nei))`` is the epilogue of the W_h GEMM;
+* ``cat([fatoms, nei])`` in front of ``W_o`` is replaced by splitting ``W_o`` by
+  columns and chaining two GEMMs;
+* the per-molecule Python mean loop is one segmented-mean kernel;
+* backward is explicit: transposed-graph gathers (fused with the ReLU mask) and
+  fixed-order weight-gradient GEMMs, no atomics.
+
+The same autograd function also serves the candidate-graph encoder (JTMPN), whose
+gathers read from ``[tree messages ; bond messages]``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _capi as K
+from . import graphprep
+from .synthetic import MPN_ATOM_FDIM, MPN_BOND_FDIM, MPN_MAX_NB
+
+ATOM_FDIM = MPN_ATOM_FDIM  # 39, fast_jtnn/mpn.py:35
+BOND_FDIM = MPN_BOND_FDIM  # 12, fast_jtnn/mpn.py:36
+MAX_NB = MPN_MAX_NB  # 6,  fast_jtnn/mpn.py:37
+
+
+def _pack_weight(w: torch.Tensor, col0: int, ncols: int) -> torch.Tensor:
+    """Columns [col0, col0+ncols) of a Linear weight as a 16-byte-row buffer [out, round4(ncols)]."""
+    w = w.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    out_f, in_f = w.shape
+    ld = K.round_ld(ncols)
+    buf = torch.empty((out_f, ld), dtype=torch.float32, device=w.device)
+    K.copy_rows(K.ptr(w, col0), in_f, buf.data_ptr(), ld, out_f, ncols)
+    return buf
+
+
+def _pack_weight_t(w: torch.Tensor, col0: int, ncols: int) -> torch.Tensor:
+    """Transpose of the same column block: [ncols, round4(out)], for the dgrad GEMMs."""
+    w = w.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    out_f, in_f = w.shape
+    ld = K.round_ld(out_f)
+    buf = torch.zeros((ncols, ld), dtype=torch.float32, device=w.device)
+    K.transpose(K.ptr(w, col0), in_f, buf.data_ptr(), ld, out_f, ncols)
+    return buf
+
+
+def as_row_buffer(t: torch.Tensor, H: int, ld: int) -> torch.Tensor:
+    """A [n, H] fp32 tensor as a row buffer with leading dimension ``ld``.
+
+    Zero-copy when ``t`` already is laid out that way (what this package's modules
+    return: a ``[:, :H]`` view of a padded buffer); otherwise one copy kernel.  No
+    kernel lets the padding columns of an input reach a real column, so their
+    content does not matter.
+    """
+    if (t.dim() == 2 and t.dtype == torch.float32 and t.shape[0] > 0 and t.stride(1) == 1
+            and t.stride(0) == ld and t.data_ptr() % 16 == 0):
+        return t.detach()
+    buf = torch.empty((t.shape[0], ld), dtype=torch.float32, device=t.device)
+    src = t.detach()
+    if src.dtype != torch.float32:
+        src = src.float()
+    if src.dim() != 2 or src.stride(1) != 1:
+        src = src.reshape(t.shape[0], -1).contiguous()
+    K.copy_rows(src.data_ptr(), src.stride(0), buf.data_ptr(), ld, t.shape[0], H)
+    return buf
+
+
+def dense_view(buf: torch.Tensor, H: int) -> torch.Tensor:
+    """[n, ld] buffer -> [n, H] view sharing its storage."""
+    return buf[:, :H]
+
+
+class _GraphMPNFunction(torch.autograd.Function):
+    """forward(W_i, W_h, W_o.weight, W_o.bias, tree_message | None) -> [n_seg, H]"""
+
+    @staticmethod
+    def forward(ctx, W_i, W_h, W_o_w, W_o_b, tree_message, prep, depth):
+        dev = W_h.device
+        H = W_h.shape[0]
+        ld = K.round_ld(H)
+        P = prep
+        NB, NA, TM = P.n_bonds, P.n_atoms, P.n_tree
+        fa_dim, fb_dim = P.atom_fdim, P.bond_in_fdim
+        train = any(ctx.needs_input_grad)
+
+        Wi = _pack_weight(W_i, 0, fb_dim)
+        Wh = _pack_weight(W_h, 0, H)
+        Woa = _pack_weight(W_o_w, 0, fa_dim)
+        Woh = _pack_weight(W_o_w, fa_dim, H)
+        tree = None
+        if TM:
+            tree = as_row_buffer(tree_message, H, ld)
+        src0 = tree.data_ptr() if TM else None  # single-source gathers read the bond rows as src0
+
+        def gather(out, msg, csr, n_rows):
+            if TM:
+                K.csr_gather_sum(out.data_ptr(), src0, TM, msg.data_ptr(), csr.rowptr.data_ptr(),
+                                 csr.col.data_ptr(), n_rows, H, ld)
+            else:
+                K.csr_gather_sum(out.data_ptr(), msg.data_ptr(), NB, None, csr.rowptr.data_ptr(),
+                                 csr.col.data_ptr(), n_rows, H, ld)
+
+        binput = K.rows(NB, ld, dev)
+        msgs = [K.rows(NB, ld, dev)]
+        # binput = W_i fbonds; message = relu(binput)            (mpn.py:87-88)
+        K.gemm_nt(P.fbonds.data_ptr(), P.fbonds.stride(0), Wi.data_ptr(), Wi.stride(0), msgs[0].data_ptr(), ld,
+                  NB, H, fb_dim, act=K.ACT_RELU, pre_out=binput.data_ptr(), ld_pre=ld)
+        neis = []
+        for _ in range(depth - 1):  # mpn.py:90-94
+            nei = K.rows(NB, ld, dev)
+            gather(nei, msgs[-1], P.bcsr, NB)
+            new = K.rows(NB, ld, dev)
+            K.gemm_nt(nei.data_ptr(), ld, Wh.data_ptr(), ld, new.data_ptr(), ld, NB, H, H,
+                      add=binput.data_ptr(), ld_add=ld, act=K.ACT_RELU)
+            neis.append(nei)
+            msgs.append(new)
+            if not train:
+                msgs = msgs[-1:]
+                neis = []
+        anei = K.rows(NA, ld, dev)  # mpn.py:96-99
+        gather(anei, msgs[-1], P.acsr, NA)
+        ah = K.rows(NA, ld, dev)
+        K.gemm_nt(P.fatoms.data_ptr(), P.fatoms.stride(0), Woa.data_ptr(), Woa.stride(0), ah.data_ptr(), ld,
+                  NA, H, fa_dim, bias=W_o_b.detach().data_ptr())
+        K.gemm_nt(anei.data_ptr(), ld, Woh.data_ptr(), ld, ah.data_ptr(), ld, NA, H, H,
+                  add=ah.data_ptr(), ld_add=ld, act=K.ACT_RELU)
+        out = K.rows(P.n_seg, ld, dev)  # mpn.py:102-107
+        K.segment_mean(out.data_ptr(), ah.data_ptr(), P.seg.data_ptr(), P.n_seg, H, ld)
+
+        if train:
+            ctx.prep, ctx.depth, ctx.H, ctx.ld = P, depth, H, ld
+            ctx.saved = (msgs, neis, anei, ah, W_h, W_o_w)
+            ctx.W_i_shape, ctx.W_o_shape = tuple(W_i.shape), tuple(W_o_w.shape)
+            ctx.has_tree = bool(TM)
+        return dense_view(out, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        P, depth, H, ld = ctx.prep, ctx.depth, ctx.H, ctx.ld
+        msgs, neis, anei, ah, W_h, W_o_w = ctx.saved
+        dev = W_h.device
+        NB, NA, TM = P.n_bonds, P.n_atoms, P.n_tree
+        fa_dim, fb_dim = P.atom_fdim, P.bond_in_fdim
+
+        WhT = _pack_weight_t(W_h, 0, H)
+        WohT = _pack_weight_t(W_o_w, fa_dim, H)
+        dW_i = torch.empty(ctx.W_i_shape, dtype=torch.float32, device=dev)
+        dW_h = torch.empty((H, H), dtype=torch.float32, device=dev)
+        dW_o = torch.empty(ctx.W_o_shape, dtype=torch.float32, device=dev)
+        db_o = torch.empty((H,), dtype=torch.float32, device=dev)
+        dtree = K.rows(TM, ld, dev) if TM else None
+
+        dout_p = as_row_buffer(dout, H, ld)
+        # through the mean readout and the ReLU of W_o                    (mpn.py:99-105)
+        dpre_o = K.rows(NA, ld, dev)
+        K.segment_mean_bwd(dpre_o.data_ptr(), dout_p.data_ptr(), ah.data_ptr(), P.seg.data_ptr(),
+                           P.seg_of.data_ptr(), NA, H, ld)
+        w_in = ctx.W_o_shape[1]
+        K.gemm_tn(dpre_o.data_ptr(), ld, P.fatoms.data_ptr(), P.fatoms.stride(0), dW_o.data_ptr(), w_in,
+                  NA, H, fa_dim, False, dev)
+        K.gemm_tn(dpre_o.data_ptr(), ld, anei.data_ptr(), ld, K.ptr(dW_o, fa_dim), w_in, NA, H, H, False, dev)
+        K.colsum(dpre_o.data_ptr(), ld, db_o.data_ptr(), NA, H, False, dev)
+        danei = K.rows(NA, ld, dev)
+        K.gemm_nt(dpre_o.data_ptr(), ld, WohT.data_ptr(), ld, danei.data_ptr(), ld, NA, H, H)
+
+        def gather_t(src, csr_t, mask, dbin, first_tree):
+            """Transposed gather of `src` rows into (tree rows | bond rows)."""
+            dpre = K.rows(NB, ld, dev)
+            K.csr_gather_sum(dpre.data_ptr(), src.data_ptr(), src.shape[0], None,
+                             K.ptr(csr_t.rowptr, TM), csr_t.col.data_ptr(), NB, H, ld,
+                             relu_mask=mask.data_ptr(), acc2=dbin.data_ptr())
+            if TM:
+                K.csr_gather_sum(dtree.data_ptr(), src.data_ptr(), src.shape[0], None,
+                                 csr_t.rowptr.data_ptr(), csr_t.col.data_ptr(), TM, H, ld,
+                                 accumulate=not first_tree)
+            return dpre
+
+        dbinput = K.rows(NB, ld, dev, zero=True)
+        dpre = gather_t(danei, P.acsr_t, msgs[-1], dbinput, True)
+        for i in range(depth - 1, 0, -1):  # message i = relu(binput + W_h nei_i)
+            nei = neis[i - 1]
+            K.gemm_tn(dpre.data_ptr(), ld, nei.data_ptr(), ld, dW_h.data_ptr(), H, NB, H, H, i != depth - 1, dev)
+            dnei = K.rows(NB, ld, dev)
+            K.gemm_nt(dpre.data_ptr(), ld, WhT.data_ptr(), ld, dnei.data_ptr(), ld, NB, H, H)
+            dpre = gather_t(dnei, P.bcsr_t, msgs[i - 1], dbinput, False)
+        if depth == 1:
+            dW_h.zero_()
+        K.gemm_tn(dbinput.data_ptr(), ld, P.fbonds.data_ptr(), P.fbonds.stride(0), dW_i.data_ptr(),
+                  ctx.W_i_shape[1], NB, H, fb_dim, False, dev)
+        dtree_out = None
+        if TM and ctx.needs_input_grad[4]:
+            dtree_out = dense_view(dtree, H)
+        return dW_i, dW_h, dW_o, db_o, dtree_out, None, None
+
+
+def _holder_prep(fatoms, fbonds, agraph, bgraph, scope, device, n_tree):
+    key = bgraph if isinstance(bgraph, torch.Tensor) else None
+    build = lambda: graphprep.prepare_mpn((fatoms, fbonds, agraph, bgraph, scope), device, n_tree)  # noqa: E731
+    if key is None:
+        return build()
+    return graphprep.cached_prep(key, ("mpn", str(device), n_tree), build)
+
+
+class MPN(nn.Module):
+    def __init__(self, hidden_size, depth):
+        super(MPN, self).__init__()
+        self.hidden_size = hidden_size
+        self.depth = depth
+        self.W_i = nn.Linear(ATOM_FDIM + BOND_FDIM, hidden_size, bias=False)
+        self.W_h = nn.Linear(hidden_size, hidden_size, bias=False)
+        self.W_o = nn.Linear(ATOM_FDIM + hidden_size, hidden_size)
+
+    def forward(self, fatoms, fbonds, agraph, bgraph, scope):
+        device = self.W_h.weight.device
+        if device.type != "cuda":
+            raise RuntimeError("fast_jtnn_hip.MPN runs on an MI355X only (module is on %s); there is no "
+                               "CPU path" % device)
+        if self.depth < 1:
+            raise ValueError("depth must be >= 1")
+        prep = _holder_prep(fatoms, fbonds, agraph, bgraph, scope, device, 0)
+        if prep.bond_in_fdim != self.W_i.in_features or prep.atom_fdim + self.hidden_size != self.W_o.in_features:
+            raise ValueError("feature widths %d/%d do not match W_i/W_o" % (prep.bond_in_fdim, prep.atom_fdim))
+        with torch.cuda.device(device):
+            return _GraphMPNFunction.apply(self.W_i.weight, self.W_h.weight, self.W_o.weight, self.W_o.bias,
+                                           None, prep, self.depth)
+
+    @staticmethod
+    def tensorize(mol_batch):
+        """Same holder as fast_jtnn/mpn.py:110-161, from abstract molecule graphs
+        (objects with ``atom_feats``, ``bonds``, ``bond_feats``) instead of SMILES:
+        RDKit feature extraction is host chemistry outside this package."""
+        from .tensorize import mpn_tensorize
+
+        return mpn_tensorize(mol_batch)

@@ -1,0 +1,179 @@
+"""Index builders: abstract graphs -> the reference's holder tuples, vectorised.
+
+Output layout is the reference's, bit for bit (checked against its own
+``JTNNEncoder.tensorize_nodes`` and against a loop-by-loop restatement of the two
+RDKit-bound tensorizers): 1-based directed bond ids with a zero padding row for
+the molecular graphs (fast_jtnn/mpn.py:112-161), message ids in node/neighbour
+order with trailing zero padding for the trees (fast_jtnn/jtnn_enc.py:54-92),
+bond ids offset by the number of tree messages for the candidate graphs
+(fast_jtnn/jtmpn.py:113-183).
+
+Inputs are feature arrays and bond lists; producing those from SMILES is RDKit
+work that stays with the caller.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+
+from .synthetic import JTMPN_MAX_NB, MPN_MAX_NB
+
+
+def _ragged_to_padded(owner: np.ndarray, value: np.ndarray, n_rows: int, width: int, what: str) -> np.ndarray:
+    """Scatter ``value`` into row ``owner`` of a zero table, filling slots left to right in input order."""
+    out = np.zeros((n_rows, width), dtype=np.int64)
+    if owner.size == 0:
+        return out
+    order = np.argsort(owner, kind="stable")
+    o, v = owner[order], value[order]
+    first = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(o, minlength=n_rows), out=first[1:])
+    slot = np.arange(o.shape[0], dtype=np.int64) - first[o]
+    if slot.size and int(slot.max()) >= width:
+        raise IndexError("%s: a row has %d neighbours, table width is %d" % (what, int(slot.max()) + 1, width))
+    out[o, slot] = v
+    return out
+
+
+def mpn_tensorize(mols: Sequence):
+    """(fatoms, fbonds, agraph, bgraph, scope) as fast_jtnn/mpn.py:110-161 builds them."""
+    n_atoms = np.asarray([m.atom_feats.shape[0] for m in mols], dtype=np.int64)
+    n_bonds = np.asarray([m.bonds.shape[0] for m in mols], dtype=np.int64)
+    atom_off = np.concatenate([[0], np.cumsum(n_atoms)])
+    total_atoms = int(atom_off[-1])
+    scope = [(int(atom_off[i]), int(n_atoms[i])) for i in range(len(mols))]
+    fatoms = np.concatenate([m.atom_feats for m in mols], axis=0).astype(np.float32)
+    bfeat = np.concatenate([m.bond_feats for m in mols], axis=0).astype(np.float32)
+    bonds = np.concatenate([m.bonds + atom_off[i] for i, m in enumerate(mols)], axis=0).astype(np.int64)
+    nb = bonds.shape[0]
+    # directed bond 2i+1 = (begin -> end), 2i+2 = (end -> begin); id 0 is padding
+    src = np.empty(2 * nb + 1, dtype=np.int64)
+    dst = np.empty(2 * nb + 1, dtype=np.int64)
+    src[0] = dst[0] = -1
+    src[1::2], dst[1::2] = bonds[:, 0], bonds[:, 1]
+    src[2::2], dst[2::2] = bonds[:, 1], bonds[:, 0]
+    fbonds = np.zeros((2 * nb + 1, fatoms.shape[1] + bfeat.shape[1]), dtype=np.float32)
+    fbonds[1:, :fatoms.shape[1]] = fatoms[src[1:]]
+    fbonds[1::2, fatoms.shape[1]:] = bfeat
+    fbonds[2::2, fatoms.shape[1]:] = bfeat
+    ids = np.arange(1, 2 * nb + 1, dtype=np.int64)
+    # in_bonds[a] = directed bonds that END in a, in creation order
+    agraph = _ragged_to_padded(dst[1:], ids, total_atoms, MPN_MAX_NB, "agraph")
+    # bgraph[b1, i] = in_bonds[x][i] unless it is the reverse bond (comes from y); slot i kept
+    bgraph = np.zeros((2 * nb + 1, MPN_MAX_NB), dtype=np.int64)
+    if nb:
+        cand = agraph[src[1:]]  # [2nb, 6] incoming bonds of the start atom
+        cand_src = np.where(cand > 0, src[np.maximum(cand, 0)], -2)
+        keep = (cand > 0) & (cand_src != dst[1:, None])
+        bgraph[1:] = np.where(keep, cand, 0)
+    return (torch.from_numpy(fatoms), torch.from_numpy(fbonds), torch.from_numpy(agraph),
+            torch.from_numpy(bgraph), scope)
+
+
+def jtenc_tensorize(tree_batch: Sequence):
+    node_batch: List = []
+    scope = []
+    for tree in tree_batch:
+        scope.append((len(node_batch), len(tree.nodes)))
+        node_batch.extend(tree.nodes)
+    return jtenc_tensorize_nodes(node_batch, scope)
+
+
+def jtenc_tensorize_nodes(node_batch: Sequence, scope):
+    """((fnode, fmess, node_graph, mess_graph, scope), mess_dict) as fast_jtnn/jtnn_enc.py:54-92."""
+    fnode = np.asarray([x.wid for x in node_batch], dtype=np.int64)
+    xs, ys = [], []
+    for x in node_batch:
+        xi = x.idx
+        for y in x.neighbors:
+            xs.append(xi)
+            ys.append(y.idx)
+    xs = np.asarray(xs, dtype=np.int64)
+    ys = np.asarray(ys, dtype=np.int64)
+    nm = xs.shape[0] + 1
+    mid = np.arange(1, nm, dtype=np.int64)
+    mess_dict = {(int(a), int(b)): int(i) for a, b, i in zip(xs, ys, mid)}
+    fmess = np.zeros(nm, dtype=np.int64)
+    fmess[1:] = xs
+    n_nodes = len(node_batch)
+    # node_graph[y] lists messages x->y in message order
+    deg_in = np.bincount(ys, minlength=n_nodes) if ys.size else np.zeros(n_nodes, dtype=np.int64)
+    kn = max(int(deg_in.max()) if n_nodes else 0, 1)
+    node_graph = _ragged_to_padded(ys, mid, n_nodes, kn, "node_graph")
+    # mess_graph[(y->z)] lists messages (x->y), x != z, in message order of (x->y):
+    # pair every message m1=(x->y) with the outgoing messages of y
+    if xs.size:
+        first_out = np.zeros(n_nodes + 1, dtype=np.int64)  # outgoing messages of a node are consecutive ids
+        np.cumsum(np.bincount(xs, minlength=n_nodes), out=first_out[1:])
+        # messages were numbered node by node only if node_batch is in idx order; map idx -> first id generally
+        order_nodes = np.asarray([x.idx for x in node_batch], dtype=np.int64)
+        out_cnt = np.asarray([len(x.neighbors) for x in node_batch], dtype=np.int64)
+        start_by_pos = np.concatenate([[0], np.cumsum(out_cnt)[:-1]]) + 1
+        start = np.zeros(n_nodes, dtype=np.int64)
+        cnt = np.zeros(n_nodes, dtype=np.int64)
+        start[order_nodes] = start_by_pos
+        cnt[order_nodes] = out_cnt
+        rep = cnt[ys]  # for each m1, number of outgoing messages of its target y
+        m1 = np.repeat(mid, rep)
+        base = np.repeat(start[ys], rep)
+        within = np.arange(m1.shape[0], dtype=np.int64) - np.repeat(np.concatenate([[0], np.cumsum(rep)[:-1]]), rep)
+        m2 = base + within
+        keep = ys[m2 - 1] != xs[m1 - 1]  # drop z == x
+        m1, m2 = m1[keep], m2[keep]
+        deg_m = np.bincount(m2, minlength=nm)
+        km = max(int(deg_m.max()), 1)
+        mess_graph = _ragged_to_padded(m2, m1, nm, km, "mess_graph")
+    else:
+        mess_graph = np.zeros((nm, 1), dtype=np.int64)
+    return (torch.from_numpy(fnode), torch.from_numpy(fmess), torch.from_numpy(node_graph),
+            torch.from_numpy(mess_graph), scope), mess_dict
+
+
+def jtmpn_tensorize(cand_batch: Sequence, mess_dict):
+    """(fatoms, fbonds, agraph, bgraph, scope) as fast_jtnn/jtmpn.py:113-183."""
+    total_mess = len(mess_dict) + 1
+    n_atoms = np.asarray([c.atom_feats.shape[0] for c in cand_batch], dtype=np.int64)
+    atom_off = np.concatenate([[0], np.cumsum(n_atoms)])
+    total_atoms = int(atom_off[-1])
+    scope = [(int(atom_off[i]), int(n_atoms[i])) for i in range(len(cand_batch))]
+    fatoms = np.concatenate([c.atom_feats for c in cand_batch], axis=0).astype(np.float32)
+    bfeat = np.concatenate([c.bond_feats for c in cand_batch], axis=0).astype(np.float32)
+    bonds = np.concatenate([c.bonds + atom_off[i] for i, c in enumerate(cand_batch)], axis=0).astype(np.int64)
+    # batch-global tree node id of every atom (-1: unlabeled), jtmpn.py:140-142
+    bid = np.concatenate([
+        np.where(c.atom_nid > 0,
+                 np.asarray([n.idx for n in c.all_nodes], dtype=np.int64)[np.maximum(c.atom_nid - 1, 0)], -1)
+        for c in cand_batch])
+    nb = bonds.shape[0]
+    src = np.empty(2 * nb, dtype=np.int64)
+    dst = np.empty(2 * nb, dtype=np.int64)
+    src[0::2], dst[0::2] = bonds[:, 0], bonds[:, 1]
+    src[1::2], dst[1::2] = bonds[:, 1], bonds[:, 0]
+    fbonds = np.zeros((2 * nb, fatoms.shape[1] + bfeat.shape[1]), dtype=np.float32)
+    fbonds[:, :fatoms.shape[1]] = fatoms[src]
+    fbonds[0::2, fatoms.shape[1]:] = bfeat
+    fbonds[1::2, fatoms.shape[1]:] = bfeat
+    # in_bonds entries in creation order.  Per undirected bond i (x,y): bond 2i ends in y, bond 2i+1
+    # ends in x, then tree message (x_bid,y_bid) ends in y, then (y_bid,x_bid) ends in x (jtmpn.py:146-162)
+    xb, yb = bid[bonds[:, 0]], bid[bonds[:, 1]]
+    labeled = (xb >= 0) & (yb >= 0) & (xb != yb)
+    m_xy = np.asarray([mess_dict.get((int(a), int(b)), 0) if l else 0 for a, b, l in zip(xb, yb, labeled)],
+                      dtype=np.int64)
+    m_yx = np.asarray([mess_dict.get((int(b), int(a)), 0) if l else 0 for a, b, l in zip(xb, yb, labeled)],
+                      dtype=np.int64)
+    owner = np.stack([bonds[:, 1], bonds[:, 0], bonds[:, 1], bonds[:, 0]], axis=1).reshape(-1)
+    value = np.stack([total_mess + 2 * np.arange(nb), total_mess + 2 * np.arange(nb) + 1, m_xy, m_yx],
+                     axis=1).reshape(-1).astype(np.int64)
+    valid = np.stack([np.ones(nb, bool), np.ones(nb, bool), m_xy > 0, m_yx > 0], axis=1).reshape(-1)
+    agraph = _ragged_to_padded(owner[valid], value[valid], total_atoms, JTMPN_MAX_NB, "agraph")
+    bgraph = np.zeros((2 * nb, JTMPN_MAX_NB), dtype=np.int64)
+    if nb:
+        cand = agraph[src]  # in_bonds of the start atom x of every directed bond
+        is_bond = cand >= total_mess
+        cand_src = np.where(is_bond, src[np.clip(cand - total_mess, 0, 2 * nb - 1)], -2)
+        keep = (cand > 0) & (~is_bond | (cand_src != dst[:, None]))
+        bgraph = np.where(keep, cand, 0)
+    return (torch.from_numpy(fatoms), torch.from_numpy(fbonds), torch.from_numpy(agraph),
+            torch.from_numpy(bgraph), scope)

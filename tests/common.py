@@ -1,0 +1,107 @@
+"""Shared helpers of the test-suite: golden fixtures, oracle models, tolerances."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN_DIR = os.path.join(HERE, "golden")
+
+# north_star tolerance: fp32 latent means / log-vars and losses within 1e-4 relative.
+# "relative" is taken against the largest magnitude of the compared tensor, so exact zeros
+# (ReLU outputs, the padding message) do not blow the ratio up.
+RTOL = 1e-4
+
+
+def rel_err(a, b) -> float:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0
+    scale = max(float(np.abs(b).max()), 1e-30)
+    return float(np.abs(a - b).max() / scale)
+
+
+def golden_cases():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "case*.npz")))
+
+
+class Golden:
+    def __init__(self, path):
+        z = np.load(path, allow_pickle=False)
+        self.z = z
+        self.name = os.path.basename(path)
+        (self.seed, self.B, self.H, self.L, self.dT, self.dG, self.V) = (int(v) for v in z["meta"])
+        self.bias_scale = float(z["bias_scale"])
+        self.mean_atoms = float(z["mean_atoms"])
+        self.sha = str(z["weights_sha256"])
+
+    def scope(self, key):
+        return [(int(a), int(b)) for a, b in self.z[key]]
+
+    def jtenc_holder(self):
+        z = self.z
+        return (torch.from_numpy(z["fnode"].astype(np.int64)), torch.from_numpy(z["fmess"].astype(np.int64)),
+                torch.from_numpy(z["node_graph"].astype(np.int64)),
+                torch.from_numpy(z["mess_graph"].astype(np.int64)), self.scope("jt_scope"))
+
+    def mpn_holder(self):
+        z = self.z
+        return (torch.from_numpy(z["fatoms"].astype(np.float32)), torch.from_numpy(z["fbonds"].astype(np.float32)),
+                torch.from_numpy(z["agraph"].astype(np.int64)), torch.from_numpy(z["bgraph"].astype(np.int64)),
+                self.scope("mpn_scope"))
+
+    def jtmpn_holder(self):
+        z = self.z
+        return (torch.from_numpy(z["c_fatoms"].astype(np.float32)),
+                torch.from_numpy(z["c_fbonds"].astype(np.float32)),
+                torch.from_numpy(z["c_agraph"].astype(np.int64)), torch.from_numpy(z["c_bgraph"].astype(np.int64)),
+                self.scope("c_scope"))
+
+    def batch_idx(self):
+        return torch.from_numpy(self.z["batch_idx"].astype(np.int64))
+
+    def mess_dict(self):
+        return {(int(a), int(b)): int(c) for a, b, c in self.z["mess_dict"]}
+
+    def trees(self):
+        from fast_jtnn_hip import synthetic
+
+        return synthetic.make_batch(self.seed, self.B, vocab_size=self.V, mean_atoms=self.mean_atoms,
+                                    with_cands=True)
+
+
+def projection(shape, seed):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy(rs.standard_normal(tuple(shape)).astype(np.float32))
+
+
+def golden_loss(model, g, tree_vecs, mol_vecs, cand_vecs):
+    """The scalar of tests/golden/make_golden.py."""
+    dev = tree_vecs.device
+    mean = torch.cat([model.T_mean(tree_vecs), model.G_mean(mol_vecs)], dim=1)
+    logvar = torch.cat([-torch.abs(model.T_var(tree_vecs)), -torch.abs(model.G_var(mol_vecs))], dim=1)
+    return ((mean * projection(mean.shape, g.seed + 101).to(dev)).sum()
+            + (logvar * projection(logvar.shape, g.seed + 102).to(dev)).sum()
+            + (cand_vecs * projection(cand_vecs.shape, g.seed + 103).to(dev)).sum()
+            / max(1, cand_vecs.shape[0]) * g.B)
+
+
+def make_oracle(g):
+    from fast_jtnn_hip import synthetic
+    from oracle.ref_encoder import OracleEncoder
+
+    m = OracleEncoder(g.V, g.H, g.L, g.dT, g.dG)
+    params = [(n, p) for n, p in m.named_parameters()]
+    synthetic.fill_params(params, seed=g.seed, bias_scale=g.bias_scale)
+    return m
+
+
+def make_hip_model(g, device):
+    from fast_jtnn_hip import JTNNVAE, synthetic
+
+    m = JTNNVAE(synthetic.FakeVocab(g.V), g.H, g.L, g.dT, g.dG)
+    synthetic.fill_params(list(m.named_parameters()), seed=g.seed, bias_scale=g.bias_scale)
+    return m.to(device)

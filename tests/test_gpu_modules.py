@@ -1,0 +1,196 @@
+"""GPU: the drop-in modules (through the C ABI) against the reference's golden vectors, against
+the CPU oracle on fresh seeded batches, and against size-independent properties at benchmark size."""
+import numpy as np
+import pytest
+import torch
+
+from common import RTOL, Golden, golden_cases, golden_loss, make_hip_model, make_oracle, rel_err
+
+pytestmark = pytest.mark.gpu
+CASES = golden_cases()
+
+
+def run_hip(g, m):
+    tree_vecs, mess, mol_vecs = m.encode(g.jtenc_holder(), g.mpn_holder())
+    cand = m.jtmpn(*g.jtmpn_holder(), mess)
+    return tree_vecs, mess, mol_vecs, cand
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: p.split("/")[-1])
+def test_forward_matches_reference_golden(path):
+    g = Golden(path)
+    m = make_hip_model(g, "cuda")
+    z = g.z
+    with torch.no_grad():
+        tree_vecs, mess, mol_vecs, cand = run_hip(g, m)
+        mean, logvar = m.encode_latent(g.jtenc_holder(), g.mpn_holder())
+        scores = m.assm_scores((g.jtmpn_holder(), g.batch_idx()), m.G_mean(mol_vecs), mess)
+    assert rel_err(tree_vecs.cpu().numpy(), z["tree_vecs"]) < RTOL
+    assert rel_err(mol_vecs.cpu().numpy(), z["mol_vecs"]) < RTOL
+    assert rel_err(mess.cpu().numpy(), z["messages"]) < RTOL
+    assert rel_err(cand.cpu().numpy(), z["cand_vecs"]) < RTOL
+    assert rel_err(mean.cpu().numpy(), z["mean"]) < RTOL
+    assert rel_err(logvar.cpu().numpy(), z["logvar"]) < RTOL
+    assert rel_err(scores.cpu().numpy(), z["scores"]) < RTOL
+    assert float(mess[0].abs().max()) == 0.0  # the padding message stays exactly zero
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: p.split("/")[-1])
+def test_backward_matches_reference_golden(path):
+    g = Golden(path)
+    m = make_hip_model(g, "cuda")
+    z = g.z
+    tree_vecs, mess, mol_vecs, cand = run_hip(g, m)
+    loss = golden_loss(m, g, tree_vecs, mol_vecs, cand)
+    assert abs(loss.item() - float(z["loss"])) <= RTOL * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    for name, p in m.named_parameters():
+        key = "gnorm/" + name
+        if key not in z.files:
+            continue
+        ref = float(z[key])
+        got = float(p.grad.double().norm())
+        assert abs(got - ref) <= 2e-4 * max(ref, 1e-6), (name, got, ref)
+        head_ref = z["ghead/" + name]
+        if np.abs(head_ref).max() > 1e-8:
+            assert rel_err(p.grad.reshape(-1)[:256].cpu().numpy(), head_ref) < 5e-4, name
+
+
+@pytest.mark.parametrize("seed,B,atoms", [(21, 32, 40.0), (22, 5, 12.0)])
+def test_full_gradients_match_oracle(seed, B, atoms):
+    """Every gradient element against the CPU oracle (autograd on the reference op sequence)."""
+    from fast_jtnn_hip import synthetic, tensorize as T
+
+    class G:  # minimal stand-in for a golden header
+        pass
+    g = G()
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = seed, B, 450, 56, 20, 3, 385, 0.05
+    trees = synthetic.make_batch(seed, B, vocab_size=g.V, mean_atoms=atoms, with_cands=True)
+    jt, mess_dict = T.jtenc_tensorize(trees)
+    mp = T.mpn_tensorize([t.mol for t in trees])
+    cands, _ = synthetic.collect_candidates(trees)
+    cj = T.jtmpn_tensorize(cands, mess_dict)
+    hip = make_hip_model(g, "cuda")
+    ora = make_oracle(g)
+
+    def run(model, dev):
+        tv, ms, mv = model.encode(jt, mp)
+        cv = model.jtmpn(*cj, ms)
+        loss = golden_loss(model, g, tv, mv, cv)
+        loss.backward()
+        return tv, ms, mv, cv, loss
+
+    a = run(hip, "cuda")
+    b = run(ora, "cpu")
+    for x, y, what in zip(a[:4], b[:4], ("tree_vecs", "messages", "mol_vecs", "cand_vecs")):
+        assert rel_err(x.detach().cpu().numpy(), y.detach().numpy()) < RTOL, what
+    assert abs(a[4].item() - b[4].item()) <= RTOL * max(1.0, abs(b[4].item()))
+    pb = dict(ora.named_parameters())
+    for name, p in hip.named_parameters():
+        if name not in pb or pb[name].grad is None:
+            continue
+        assert p.grad is not None, name
+        e = rel_err(p.grad.cpu().numpy(), pb[name].grad.numpy())
+        assert e < 5e-4, (name, e)
+
+
+def test_inference_equals_training_forward_and_is_deterministic():
+    g = Golden(CASES[2])
+    m = make_hip_model(g, "cuda")
+    with torch.no_grad():
+        a = run_hip(g, m)
+    b = run_hip(g, m)
+    c = run_hip(g, m)
+    for x, y, w in zip(a, b, c):
+        assert torch.equal(x, y.detach()) and torch.equal(y.detach(), w.detach())
+    # gradients are bitwise reproducible too (no atomics anywhere)
+    grads = []
+    for _ in range(2):
+        m.zero_grad()
+        tv, ms, mv, cv = run_hip(g, m)
+        golden_loss(m, g, tv, mv, cv).backward()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+def test_benchmark_size_properties():
+    """B=1024 (the benchmark batch): encoding the batch in two halves gives the same per-molecule
+    vectors as encoding it whole; molecule order does not matter."""
+    from fast_jtnn_hip import synthetic, tensorize as T
+
+    class G:
+        pass
+    g = G()
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = 0, 1024, 450, 56, 20, 3, 385, 0.0
+    m = make_hip_model(g, "cuda")
+
+    def encode(trees):
+        synthetic.set_batch_nodeID(trees)
+        jt, _ = T.jtenc_tensorize(trees)
+        mp = T.mpn_tensorize([t.mol for t in trees])
+        with torch.no_grad():
+            tv, ms, mv = m.encode(jt, mp)
+        return tv.clone(), mv.clone(), ms
+
+    trees = synthetic.make_batch(0, 1024, vocab_size=385)
+    tv, mv, ms = encode(trees)
+    assert tv.shape == (1024, 450) and mv.shape == (1024, 450)
+    assert torch.isfinite(tv).all() and torch.isfinite(mv).all() and torch.isfinite(ms).all()
+    tv1, mv1, _ = encode(trees[:512])
+    tv2, mv2, _ = encode(trees[512:])
+    assert rel_err(torch.cat([tv1, tv2]).cpu().numpy(), tv.cpu().numpy()) < 1e-5
+    assert rel_err(torch.cat([mv1, mv2]).cpu().numpy(), mv.cpu().numpy()) < 1e-5
+    perm = np.random.RandomState(1).permutation(1024)
+    tvp, mvp, _ = encode([trees[i] for i in perm])
+    assert rel_err(tvp.cpu().numpy(), tv.cpu().numpy()[perm]) < 1e-5
+    assert rel_err(mvp.cpu().numpy(), mv.cpu().numpy()[perm]) < 1e-5
+
+
+def test_edge_cases():
+    """Single-node tree (no messages besides the padding row), molecule without bonds,
+    depth 1, and a tiny hidden size that is not a multiple of 4."""
+    from fast_jtnn_hip import JTNNEncoder, MPN, synthetic, tensorize as T
+    from oracle.ref_encoder import OracleJTNNEncoder, OracleMPN
+
+    rs = np.random.RandomState(0)
+    for H, depth in ((450, 1), (30, 3), (7, 2)):
+        mols = [synthetic.MolGraph(synthetic._one_hot_blocks(rs, 1, (23, 6, 5, 4), 1), np.zeros((0, 2), np.int64),
+                                   np.zeros((0, 12), np.float32)),
+                synthetic.make_mol(rs, 9.0, 1.0, 5, 12)]
+        holder = T.mpn_tensorize(mols)
+        hip, ora = MPN(H, depth).cuda(), OracleMPN(H, depth)
+        synthetic.fill_params(list(hip.named_parameters()), 3, 0.1)
+        synthetic.fill_params(list(ora.named_parameters()), 3, 0.1)
+        a = hip(*holder)
+        b = ora(*holder)
+        assert rel_err(a.detach().cpu().numpy(), b.detach().numpy()) < RTOL
+        a.sum().backward(); b.sum().backward()
+        for (n, p), (_, q) in zip(hip.named_parameters(), ora.named_parameters()):
+            assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < 5e-4, (H, depth, n)
+        # trees: one single-node tree and one two-node tree
+        t1 = synthetic.Tree([synthetic.TreeNode(1, 2)], mols[0])
+        n1, n2 = synthetic.TreeNode(1, 0), synthetic.TreeNode(2, 4)
+        n1.neighbors.append(n2); n2.neighbors.append(n1)
+        t2 = synthetic.Tree([n1, n2], mols[1])
+        trees = [t1, t2]
+        synthetic.set_batch_nodeID(trees)
+        jt, _ = T.jtenc_tensorize(trees)
+        hip_e = JTNNEncoder(H, max(depth, 1), torch.nn.Embedding(5, H)).cuda()
+        ora_e = OracleJTNNEncoder(H, max(depth, 1), torch.nn.Embedding(5, H))
+        synthetic.fill_params(list(hip_e.named_parameters()), 4, 0.1)
+        synthetic.fill_params(list(ora_e.named_parameters()), 4, 0.1)
+        (tv, ms), (tvo, mso) = hip_e(*jt), ora_e(*jt)
+        assert rel_err(tv.detach().cpu().numpy(), tvo.detach().numpy()) < RTOL
+        assert rel_err(ms.detach().cpu().numpy(), mso.detach().numpy()) < RTOL
+        (tv.sum() + ms.sum()).backward(); (tvo.sum() + mso.sum()).backward()
+        for (n, p), (_, q) in zip(hip_e.named_parameters(), ora_e.named_parameters()):
+            assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < 5e-4, (H, depth, n)
+
+
+def test_out_of_range_index_is_rejected_on_the_host():
+    from fast_jtnn_hip import MPN
+    m = MPN(16, 2).cuda()
+    with pytest.raises(IndexError):
+        m(torch.zeros(2, 39), torch.zeros(3, 51), torch.zeros(2, 6).long(),
+          torch.tensor([[0] * 6, [7, 0, 0, 0, 0, 0], [0] * 6]), [(0, 2)])

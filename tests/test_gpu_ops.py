@@ -1,0 +1,317 @@
+"""GPU: every kernel entry point of the C ABI against a CPU fp64/fp32 restatement of the op."""
+import numpy as np
+import pytest
+import torch
+
+from common import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from fast_jtnn_hip import _capi
+    assert torch.cuda.is_available()
+    return _capi
+
+
+def dev_rows(x, ld):
+    """numpy [n, H] -> padded device buffer [n, ld] with NaN-free garbage in the padding."""
+    n, h = x.shape
+    buf = torch.full((n, ld), 7.5, dtype=torch.float32, device="cuda")
+    buf[:, :h] = torch.from_numpy(x).cuda()
+    return buf
+
+
+@pytest.mark.parametrize("M,N,Kd", [(1, 450, 450), (129, 450, 450), (1000, 450, 450), (257, 96, 96),
+                                    (300, 450, 51), (64, 450, 39), (515, 33, 7)])
+def test_gemm_nt_plain(K, M, N, Kd):
+    rs = np.random.RandomState(M + N + Kd)
+    A = rs.standard_normal((M, Kd)).astype(np.float32)
+    W = rs.standard_normal((N, Kd)).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    add = rs.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias + add
+    lda, ldc = K.round_ld(Kd), K.round_ld(N)
+    for aligned in (True, False):
+        if aligned:
+            Ad, Wd = dev_rows(A, lda), dev_rows(W, lda)
+            a_ld = w_ld = lda
+        else:
+            Ad, Wd = torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda()
+            a_ld = w_ld = Kd
+        C = torch.full((M, ldc), -3.0, device="cuda")
+        pre = torch.full((M, ldc), -3.0, device="cuda")
+        K.gemm_nt(Ad.data_ptr(), a_ld, Wd.data_ptr(), w_ld, C.data_ptr(), ldc, M, N, Kd,
+                  bias=torch.from_numpy(bias).cuda().data_ptr(), add=dev_rows(add, ldc).data_ptr(), ld_add=ldc,
+                  act=K.ACT_RELU, pre_out=pre.data_ptr(), ld_pre=ldc)
+        torch.cuda.synchronize()
+        assert rel_err(pre[:, :N].cpu().numpy(), ref) < 2e-6
+        assert rel_err(C[:, :N].cpu().numpy(), np.maximum(ref, 0)) < 2e-6
+        assert float(C[:, N:].abs().max()) == 0.0 if ldc > N else True
+
+
+def test_gemm_nt_table_addend_and_activations(K):
+    rs = np.random.RandomState(5)
+    M, N, Kd, V = 333, 450, 450, 17
+    ld = K.round_ld(N)
+    A = rs.standard_normal((M, Kd)).astype(np.float32) * 0.1
+    W = rs.standard_normal((N, Kd)).astype(np.float32) * 0.1
+    tab = rs.standard_normal((V, N)).astype(np.float32)
+    idx = rs.randint(0, V, size=M).astype(np.int32)
+    pre = A.astype(np.float64) @ W.astype(np.float64).T + tab[idx]
+    for act, fn in ((K.ACT_SIGMOID, lambda v: 1 / (1 + np.exp(-v))), (K.ACT_TANH, np.tanh), (K.ACT_NONE, lambda v: v)):
+        C = torch.empty((M, ld), device="cuda")
+        K.gemm_nt(dev_rows(A, ld).data_ptr(), ld, dev_rows(W, ld).data_ptr(), ld, C.data_ptr(), ld, M, N, Kd,
+                  add=dev_rows(tab, ld).data_ptr(), ld_add=ld, add_idx=torch.from_numpy(idx).cuda().data_ptr(),
+                  act=act)
+        torch.cuda.synchronize()
+        assert rel_err(C[:, :N].cpu().numpy(), fn(pre)) < 3e-6
+
+
+def test_gemm_nt_gru_blend_and_mul_acc(K):
+    rs = np.random.RandomState(6)
+    M, N = 200, 450
+    ld = K.round_ld(N)
+    G = rs.standard_normal((M, N)).astype(np.float32) * 0.1
+    W = rs.standard_normal((N, N)).astype(np.float32) * 0.1
+    tab = rs.standard_normal((9, N)).astype(np.float32)
+    idx = rs.randint(0, 9, size=M).astype(np.int32)
+    z = rs.rand(M, N).astype(np.float32)
+    s = rs.standard_normal((M, N)).astype(np.float32)
+    p_ref = np.tanh(G.astype(np.float64) @ W.astype(np.float64).T + tab[idx])
+    h_ref = (1 - z) * s + z * p_ref
+    h_ref[0] = 0
+    P = torch.empty((M, ld), device="cuda")
+    Hn = torch.empty((M, ld), device="cuda")
+    K.gemm_nt(dev_rows(G, ld).data_ptr(), ld, dev_rows(W, ld).data_ptr(), ld, P.data_ptr(), ld, M, N, N,
+              add=dev_rows(tab, ld).data_ptr(), ld_add=ld, add_idx=torch.from_numpy(idx).cuda().data_ptr(),
+              mode=K.EPI_GRU_BLEND, aux0=dev_rows(z, ld).data_ptr(), aux1=dev_rows(s, ld).data_ptr(),
+              out2=Hn.data_ptr(), ld_aux=ld)
+    torch.cuda.synchronize()
+    assert rel_err(P[:, :N].cpu().numpy(), p_ref) < 3e-6
+    assert rel_err(Hn[:, :N].cpu().numpy(), h_ref) < 3e-6
+    assert float(Hn[:, N:].abs().max()) == 0.0 and float(Hn[0].abs().max()) == 0.0
+    # multiply-accumulate epilogue
+    t = rs.standard_normal((M, N)).astype(np.float32)
+    acc0 = rs.standard_normal((M, N)).astype(np.float32)
+    acc = dev_rows(acc0, ld)
+    C = torch.empty((M, ld), device="cuda")
+    K.gemm_nt(dev_rows(G, ld).data_ptr(), ld, dev_rows(W, ld).data_ptr(), ld, C.data_ptr(), ld, M, N, N,
+              mode=K.EPI_MUL_ACC, aux0=dev_rows(t, ld).data_ptr(), out2=acc.data_ptr(), ld_aux=ld)
+    torch.cuda.synchronize()
+    c_ref = G.astype(np.float64) @ W.astype(np.float64).T
+    assert rel_err(C[:, :N].cpu().numpy(), c_ref) < 3e-6
+    assert rel_err(acc[:, :N].cpu().numpy(), acc0 + c_ref * t) < 3e-6
+
+
+@pytest.mark.parametrize("M,N,Kd", [(1000, 450, 450), (70000, 450, 450), (5000, 450, 39), (31, 96, 51),
+                                    (4097, 450, 44)])
+def test_gemm_tn_and_colsum(K, M, N, Kd):
+    rs = np.random.RandomState(M)
+    X = rs.standard_normal((M, N)).astype(np.float32)
+    Y = rs.standard_normal((M, Kd)).astype(np.float32)
+    ref = X.astype(np.float64).T @ Y.astype(np.float64)
+    ldx, ldy = K.round_ld(N), K.round_ld(Kd)
+    base = rs.standard_normal((N, Kd + 5)).astype(np.float32)
+    dW = torch.from_numpy(base.copy()).cuda()
+    Xd, Yd = dev_rows(X, ldx), dev_rows(Y, ldy)
+    K.gemm_tn(Xd.data_ptr(), ldx, Yd.data_ptr(), ldy, dW.data_ptr(), Kd + 5, M, N, Kd, False, "cuda")
+    torch.cuda.synchronize()
+    got = dW.cpu().numpy()
+    scale = np.sqrt(M)
+    assert np.abs(got[:, :Kd] - ref).max() / scale < 2e-5
+    assert np.array_equal(got[:, Kd:], base[:, Kd:])  # columns beyond K untouched (strided destination)
+    K.gemm_tn(Xd.data_ptr(), ldx, Yd.data_ptr(), ldy, dW.data_ptr(), Kd + 5, M, N, Kd, True, "cuda")
+    torch.cuda.synchronize()
+    assert np.abs(dW.cpu().numpy()[:, :Kd] - 2 * ref).max() / scale < 4e-5
+    # bitwise reproducible
+    dW2 = torch.zeros_like(dW)
+    dW3 = torch.zeros_like(dW)
+    K.gemm_tn(Xd.data_ptr(), ldx, Yd.data_ptr(), ldy, dW2.data_ptr(), Kd + 5, M, N, Kd, False, "cuda")
+    K.gemm_tn(Xd.data_ptr(), ldx, Yd.data_ptr(), ldy, dW3.data_ptr(), Kd + 5, M, N, Kd, False, "cuda")
+    torch.cuda.synchronize()
+    assert torch.equal(dW2, dW3)
+    out = torch.zeros(N, device="cuda")
+    K.colsum(Xd.data_ptr(), ldx, out.data_ptr(), M, N, False, "cuda")
+    torch.cuda.synchronize()
+    assert np.abs(out.cpu().numpy() - X.astype(np.float64).sum(0)).max() / scale < 2e-5
+
+
+def test_transpose_and_copy_rows(K):
+    rs = np.random.RandomState(1)
+    W = rs.standard_normal((450, 489)).astype(np.float32)
+    Wd = torch.from_numpy(W).cuda()
+    T = torch.zeros((450, 452), device="cuda")
+    K.transpose(K.ptr(Wd, 39), 489, T.data_ptr(), 452, 450, 450)  # columns 39.. of W_o, transposed
+    P = torch.empty((450, 40), device="cuda")
+    K.copy_rows(Wd.data_ptr(), 489, P.data_ptr(), 40, 450, 39)
+    torch.cuda.synchronize()
+    assert np.array_equal(T[:, :450].cpu().numpy(), W[:, 39:].T)
+    assert np.array_equal(P[:, :39].cpu().numpy(), W[:, :39]) and float(P[:, 39].abs().max()) == 0.0
+
+
+def random_csr(rs, n_rows, n_src, max_deg):
+    deg = rs.randint(0, max_deg + 1, size=n_rows)
+    rp = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    col = rs.randint(1, n_src, size=int(rp[-1]))
+    return rp, col
+
+
+@pytest.mark.parametrize("H", [450, 96, 7])
+def test_csr_gather_sum_variants(K, H):
+    rs = np.random.RandomState(H)
+    ld = K.round_ld(H)
+    n0, n1, n_rows = 40, 70, 333
+    s0 = rs.standard_normal((n0, H)).astype(np.float32)
+    s1 = rs.standard_normal((n1, H)).astype(np.float32)
+    cat = np.concatenate([s0, s1])
+    rp, col = random_csr(rs, n_rows, n0 + n1, 9)
+    ref = np.zeros((n_rows, H), dtype=np.float64)
+    for i in range(n_rows):
+        for e in range(rp[i], rp[i + 1]):
+            ref[i] += cat[col[e]]
+    rpd = torch.from_numpy(rp.astype(np.int32)).cuda()
+    cold = torch.from_numpy(col.astype(np.int32)).cuda()
+    out = torch.full((n_rows, ld), 9.0, device="cuda")
+    K.csr_gather_sum(out.data_ptr(), dev_rows(s0, ld).data_ptr(), n0, dev_rows(s1, ld).data_ptr(), rpd.data_ptr(),
+                     cold.data_ptr(), n_rows, H, ld)
+    torch.cuda.synchronize()
+    assert rel_err(out[:, :H].cpu().numpy(), ref) < 1e-6
+    if ld > H:
+        assert float(out[:, H:].abs().max()) == 0.0
+    # single source + relu mask + accumulate + second accumulator
+    mask = rs.standard_normal((n_rows, H)).astype(np.float32)
+    prev = rs.standard_normal((n_rows, H)).astype(np.float32)
+    acc2 = rs.standard_normal((n_rows, H)).astype(np.float32)
+    outd, acc2d = dev_rows(prev, ld), dev_rows(acc2, ld)
+    K.csr_gather_sum(outd.data_ptr(), dev_rows(cat, ld).data_ptr(), n0 + n1, None, rpd.data_ptr(), cold.data_ptr(),
+                     n_rows, H, ld, relu_mask=dev_rows(mask, ld).data_ptr(), accumulate=True,
+                     acc2=acc2d.data_ptr())
+    torch.cuda.synchronize()
+    want = ref * (mask > 0) + prev
+    assert rel_err(outd[:, :H].cpu().numpy(), want) < 1e-6
+    assert rel_err(acc2d[:, :H].cpu().numpy(), acc2 + want) < 1e-6
+
+
+def test_segment_mean_and_backward_and_slab_sum(K):
+    rs = np.random.RandomState(3)
+    H, ld = 450, 452
+    lens = rs.randint(1, 60, size=50)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    n = int(lens.sum())
+    rows = rs.standard_normal((n, H)).astype(np.float32)
+    seg = np.stack([starts, lens], 1).astype(np.int32)
+    segd = torch.from_numpy(seg).cuda()
+    out = torch.empty((50, ld), device="cuda")
+    K.segment_mean(out.data_ptr(), dev_rows(rows, ld).data_ptr(), segd.data_ptr(), 50, H, ld)
+    ref = np.stack([rows[s:s + l].astype(np.float64).mean(0) for s, l in zip(starts, lens)])
+    torch.cuda.synchronize()
+    assert rel_err(out[:, :H].cpu().numpy(), ref) < 1e-6
+    dout = rs.standard_normal((50, H)).astype(np.float32)
+    seg_of = np.repeat(np.arange(50), lens).astype(np.int32)
+    seg_of[5] = -1
+    drows = torch.empty((n, ld), device="cuda")
+    K.segment_mean_bwd(drows.data_ptr(), dev_rows(dout, ld).data_ptr(), dev_rows(rows, ld).data_ptr(),
+                       segd.data_ptr(), torch.from_numpy(seg_of).cuda().data_ptr(), n, H, ld)
+    torch.cuda.synchronize()
+    want = dout[np.maximum(seg_of, 0)] / lens[np.maximum(seg_of, 0)][:, None] * (rows > 0)
+    want[5] = 0
+    assert rel_err(drows[:, :H].cpu().numpy(), want) < 1e-6
+    X = rs.standard_normal((7, 33, H)).astype(np.float32)
+    Xd = torch.zeros((7, 33, ld), device="cuda")
+    Xd[:, :, :H] = torch.from_numpy(X).cuda()
+    o = torch.empty((33, ld), device="cuda")
+    K.slab_sum(o.data_ptr(), Xd.data_ptr(), 7, 33 * ld, 33, H, ld)
+    torch.cuda.synchronize()
+    assert rel_err(o[:, :H].cpu().numpy(), X.astype(np.float64).sum(0)) < 1e-6
+
+
+def test_gru_kernels(K):
+    rs = np.random.RandomState(4)
+    H, ld, NM, V = 450, 452, 211, 13
+    h = rs.standard_normal((NM, H)).astype(np.float32) * 0.5
+    h[0] = 0
+    Uh = rs.standard_normal((NM, H)).astype(np.float32)
+    Pr = rs.standard_normal((V, H)).astype(np.float32)
+    Pz = rs.standard_normal((V, H)).astype(np.float32)
+    Ph = rs.standard_normal((V, H)).astype(np.float32)
+    wid = rs.randint(0, V, size=NM).astype(np.int32)
+    rp, col = random_csr(rs, NM, NM, 5)
+    rp[1:] -= rp[1]  # row 0 reads nothing
+    col = col[-int(rp[-1]):] if rp[-1] else col[:0]
+    sig = lambda v: 1 / (1 + np.exp(-v))  # noqa: E731
+    s_ref = np.zeros((NM, H)); g_ref = np.zeros((NM, H)); t_ref = np.zeros((NM, H))
+    for m in range(NM):
+        for e in range(rp[m], rp[m + 1]):
+            j = col[e]
+            r = sig(Pr[wid[m]].astype(np.float64) + Uh[j])
+            s_ref[m] += h[j]; g_ref[m] += r * h[j]; t_ref[m] += r * (1 - r) * h[j]
+    dv = lambda x: dev_rows(x.astype(np.float32), ld)  # noqa: E731
+    i32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).cuda()  # noqa: E731
+    hd, Ud, Prd, widd, rpd, cold = dv(h), dv(Uh), dv(Pr), i32(wid), i32(rp), i32(col)
+    s, g, t = (torch.empty((NM, ld), device="cuda") for _ in range(3))
+    K.gru_gate_gather(hd.data_ptr(), Ud.data_ptr(), Prd.data_ptr(), widd.data_ptr(), rpd.data_ptr(),
+                      cold.data_ptr(), s.data_ptr(), g.data_ptr(), t.data_ptr(), NM, H, ld)
+    s2, g2 = (torch.empty((NM, ld), device="cuda") for _ in range(2))
+    K.gru_gate_gather(hd.data_ptr(), Ud.data_ptr(), Prd.data_ptr(), widd.data_ptr(), rpd.data_ptr(),
+                      cold.data_ptr(), s2.data_ptr(), g2.data_ptr(), None, NM, H, ld)
+    torch.cuda.synchronize()
+    assert rel_err(s[:, :H].cpu().numpy(), s_ref) < 1e-6
+    assert rel_err(g[:, :H].cpu().numpy(), g_ref) < 2e-6
+    assert rel_err(t[:, :H].cpu().numpy(), t_ref) < 2e-6
+    assert torch.equal(s, s2) and torch.equal(g, g2)
+    # iteration 0
+    z, p, h1 = (torch.empty((NM, ld), device="cuda") for _ in range(3))
+    K.gru_iter0(dv(Pz).data_ptr(), dv(Ph).data_ptr(), widd.data_ptr(), z.data_ptr(), p.data_ptr(), h1.data_ptr(),
+                NM, H, ld)
+    torch.cuda.synchronize()
+    z_ref, p_ref = sig(Pz[wid].astype(np.float64)), np.tanh(Ph[wid].astype(np.float64))
+    h_ref = z_ref * p_ref
+    h_ref[0] = 0
+    assert rel_err(z[:, :H].cpu().numpy(), z_ref) < 2e-6 and rel_err(p[:, :H].cpu().numpy(), p_ref) < 2e-6
+    assert rel_err(h1[:, :H].cpu().numpy(), h_ref) < 2e-6
+    # pointwise backward
+    dh = rs.standard_normal((NM, H)).astype(np.float32)
+    zz, pp, ss = rs.rand(NM, H).astype(np.float32), np.tanh(rs.standard_normal((NM, H))).astype(np.float32), s_ref
+    dz, dp, ds = (torch.empty((NM, ld), device="cuda") for _ in range(3))
+    K.gru_bwd_pointwise(dv(dh).data_ptr(), dv(zz).data_ptr(), dv(pp).data_ptr(), dv(ss).data_ptr(), dz.data_ptr(),
+                        dp.data_ptr(), ds.data_ptr(), NM, H, ld)
+    torch.cuda.synchronize()
+    d = dh.astype(np.float64).copy(); d[0] = 0
+    assert rel_err(dz[:, :H].cpu().numpy(), d * (pp - ss) * zz * (1 - zz)) < 2e-6
+    assert rel_err(dp[:, :H].cpu().numpy(), d * zz * (1 - pp.astype(np.float64) ** 2)) < 2e-6
+    assert rel_err(ds[:, :H].cpu().numpy(), d * (1 - zz)) < 2e-6
+    # gather backward on the transposed graph
+    from fast_jtnn_hip import graphprep
+    trp, tcol = graphprep.transpose_csr(rp.astype(np.int64), col.astype(np.int64), NM)
+    dg = rs.standard_normal((NM, H)).astype(np.float32)
+    dsv = rs.standard_normal((NM, H)).astype(np.float32)
+    du_ref = np.zeros((NM, H)); dh_ref = np.zeros((NM, H))
+    for m in range(NM):
+        for e in range(rp[m], rp[m + 1]):
+            j = col[e]
+            r = sig(Pr[wid[m]].astype(np.float64) + Uh[j])
+            du_ref[j] += dg[m] * r * (1 - r) * h[j]
+            dh_ref[j] += dsv[m] + dg[m] * r
+    du, dhd = (torch.empty((NM, ld), device="cuda") for _ in range(2))
+    K.gru_bwd_gather(hd.data_ptr(), Ud.data_ptr(), Prd.data_ptr(), widd.data_ptr(), dv(dg).data_ptr(),
+                     dv(dsv).data_ptr(), i32(trp).data_ptr(), i32(tcol).data_ptr(), du.data_ptr(), dhd.data_ptr(),
+                     NM, H, ld)
+    torch.cuda.synchronize()
+    assert rel_err(du[:, :H].cpu().numpy(), du_ref) < 3e-6
+    assert rel_err(dhd[:, :H].cpu().numpy(), dh_ref) < 3e-6
+
+
+def test_row_dot(K):
+    rs = np.random.RandomState(8)
+    H, ld, NC, B = 450, 452, 77, 9
+    q = rs.standard_normal((B, H)).astype(np.float32)
+    c = rs.standard_normal((NC, H)).astype(np.float32)
+    own = rs.randint(0, B, size=NC).astype(np.int32)
+    sc = torch.empty(NC, device="cuda")
+    K.row_dot(sc.data_ptr(), dev_rows(q, ld).data_ptr(), torch.from_numpy(own).cuda().data_ptr(),
+              dev_rows(c, ld).data_ptr(), NC, H, ld)
+    torch.cuda.synchronize()
+    assert rel_err(sc.cpu().numpy(), (q[own].astype(np.float64) * c).sum(1)) < 2e-6
