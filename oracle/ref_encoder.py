@@ -14,8 +14,11 @@ Follows:
   fast_jtnn/jtnn_vae.py:56-65     encode_latent (latent heads)
   fast_jtnn/jtnn_vae.py:105-114   assm scoring (bilinear candidate score)
 
-The only deliberate difference: ``create_var`` (nnutils.py:6-10) moves tensors to
-CUDA unconditionally; here everything stays on the CPU.
+The only deliberate differences: ``create_var`` (nnutils.py:6-10) moves tensors to
+CUDA unconditionally, here everything stays on the CPU; and the two tensors the
+reference creates itself (the zero start state and the row-0 mask) take the
+module's dtype, so that ``.double()`` gives an fp64 run of the same op sequence
+(used by the tests to tell kernel error from ReLU-kink noise).
 
 Pinned by tests/golden/*.npz, which hold outputs of the reference itself
 (imported from its source tree when the fixtures were generated).
@@ -62,7 +65,7 @@ class OracleGraphGRU(nn.Module):
         self.W_h = nn.Linear(input_size + hidden_size, hidden_size)
 
     def forward(self, h, x, mess_graph):
-        mask = torch.ones(h.size(0), 1)
+        mask = torch.ones(h.size(0), 1, dtype=h.dtype)  # dtype follows the module so it also runs in fp64
         mask[0] = 0  # jtnn_enc.py:108-109: row 0 is the padding message
         for _ in range(self.depth):  # jtnn_enc.py:111-126
             h_nei = index_select_ND(h, 0, mess_graph)
@@ -87,7 +90,8 @@ class OracleJTNNEncoder(nn.Module):
         self.GRU = OracleGraphGRU(hidden_size, hidden_size, depth=depth)
 
     def forward(self, fnode, fmess, node_graph, mess_graph, scope):
-        messages = torch.zeros(mess_graph.size(0), self.hidden_size)  # jtnn_enc.py:25
+        messages = torch.zeros(mess_graph.size(0), self.hidden_size,
+                               dtype=self.embedding.weight.dtype)  # jtnn_enc.py:25
         fnode = self.embedding(fnode)  # jtnn_enc.py:27-29
         fmess = index_select_ND(fnode, 0, fmess)
         messages = self.GRU(messages, fmess, mess_graph)

@@ -24,6 +24,15 @@ def rel_err(a, b) -> float:
     return float(np.abs(a - b).max() / scale)
 
 
+def fro_err(a, b) -> float:
+    """||a - b||_F / ||b||_F: insensitive to the handful of ReLU units whose pre-activation
+    is within rounding of zero and therefore switch differently on two platforms."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
 def golden_cases():
     return sorted(glob.glob(os.path.join(GOLDEN_DIR, "case*.npz")))
 

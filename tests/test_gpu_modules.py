@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import RTOL, Golden, golden_cases, golden_loss, make_hip_model, make_oracle, rel_err
+from common import RTOL, Golden, fro_err, golden_cases, golden_loss, make_hip_model, make_oracle, rel_err
 
 pytestmark = pytest.mark.gpu
 CASES = golden_cases()
@@ -56,9 +56,7 @@ def test_backward_matches_reference_golden(path):
             assert rel_err(p.grad.reshape(-1)[:256].cpu().numpy(), head_ref) < 5e-4, name
 
 
-@pytest.mark.parametrize("seed,B,atoms", [(21, 32, 40.0), (22, 5, 12.0)])
-def test_full_gradients_match_oracle(seed, B, atoms):
-    """Every gradient element against the CPU oracle (autograd on the reference op sequence)."""
+def _seeded_problem(seed, B, atoms):
     from fast_jtnn_hip import synthetic, tensorize as T
 
     class G:  # minimal stand-in for a golden header
@@ -70,18 +68,32 @@ def test_full_gradients_match_oracle(seed, B, atoms):
     mp = T.mpn_tensorize([t.mol for t in trees])
     cands, _ = synthetic.collect_candidates(trees)
     cj = T.jtmpn_tensorize(cands, mess_dict)
+    return g, jt, mp, cj
+
+
+@pytest.mark.parametrize("seed,B,atoms", [(21, 32, 40.0), (22, 5, 12.0)])
+def test_end_to_end_gradients_match_oracle(seed, B, atoms):
+    """Whole encoder path, every gradient tensor, against the fp32 CPU oracle.
+
+    Bounds: forward values and the loss at the path's 1e-4.  Gradient tensors as a whole
+    (Frobenius) at 1e-4, except the candidate-graph weights: upstream of them sit ~1e8 ReLU units
+    fed by 20 recurrent fp32 iterations, and the few units whose pre-activation lies within
+    rounding of zero switch differently on any two fp32 implementations (the fp32 CPU oracle
+    against its own fp64 run shows 5e-4 there).  The next test removes that noise source.
+    """
+    g, jt, mp, cj = _seeded_problem(seed, B, atoms)
     hip = make_hip_model(g, "cuda")
     ora = make_oracle(g)
 
-    def run(model, dev):
+    def run(model):
         tv, ms, mv = model.encode(jt, mp)
         cv = model.jtmpn(*cj, ms)
         loss = golden_loss(model, g, tv, mv, cv)
         loss.backward()
         return tv, ms, mv, cv, loss
 
-    a = run(hip, "cuda")
-    b = run(ora, "cpu")
+    a = run(hip)
+    b = run(ora)
     for x, y, what in zip(a[:4], b[:4], ("tree_vecs", "messages", "mol_vecs", "cand_vecs")):
         assert rel_err(x.detach().cpu().numpy(), y.detach().numpy()) < RTOL, what
     assert abs(a[4].item() - b[4].item()) <= RTOL * max(1.0, abs(b[4].item()))
@@ -90,8 +102,65 @@ def test_full_gradients_match_oracle(seed, B, atoms):
         if name not in pb or pb[name].grad is None:
             continue
         assert p.grad is not None, name
-        e = rel_err(p.grad.cpu().numpy(), pb[name].grad.numpy())
-        assert e < 5e-4, (name, e)
+        f = fro_err(p.grad.cpu().numpy(), pb[name].grad.numpy())
+        assert f < (1e-3 if name.startswith("jtmpn.") else RTOL), (name, f)
+
+
+def test_component_gradients_match_fp64_oracle():
+    """Each module alone, fed bit-identical inputs and upstream gradients, against the oracle's
+    op sequence run in fp64: what is left is the kernels' own rounding."""
+    from common import projection
+
+    g, jt, mp, cj = _seeded_problem(21, 32, 40.0)
+    hip = make_hip_model(g, "cuda")
+    o64 = make_oracle(g).double()
+
+    def grads(mod):
+        return {n: p.grad.detach().cpu().numpy() for n, p in mod.named_parameters() if p.grad is not None}
+
+    # tree encoder: no ReLU upstream of the recurrent part
+    tv64, ms64 = o64.jtnn(*jt)
+    R1, R2 = projection(tv64.shape, 1), projection(ms64.shape, 2) * 0.01
+    ((tv64 * R1.double()).sum() + (ms64 * R2.double()).sum()).backward()
+    tv, ms = hip.jtnn(*jt)
+    ((tv * R1.cuda()).sum() + (ms * R2.cuda()).sum()).backward()
+    assert rel_err(ms.detach().cpu().numpy(), ms64.detach().numpy()) < 2e-6
+    assert rel_err(tv.detach().cpu().numpy(), tv64.detach().numpy()) < 5e-6
+    ref = grads(o64.jtnn)
+    for n, v in grads(hip.jtnn).items():
+        assert rel_err(v, ref[n]) < 5e-6, (n, rel_err(v, ref[n]))
+
+    # molecular graph MPN
+    mp64 = (mp[0].double(), mp[1].double()) + tuple(mp[2:])
+    mv64 = o64.mpn(*mp64)
+    R3 = projection(mv64.shape, 3)
+    (mv64 * R3.double()).sum().backward()
+    mv = hip.mpn(*mp)
+    (mv * R3.cuda()).sum().backward()
+    assert rel_err(mv.detach().cpu().numpy(), mv64.detach().numpy()) < 2e-6
+    ref = grads(o64.mpn)
+    for n, v in grads(hip.mpn).items():
+        assert fro_err(v, ref[n]) < 1e-5, (n, fro_err(v, ref[n]))
+
+    # candidate graphs, tree messages given (the oracle's, rounded to fp32 once)
+    base = ms64.detach().float()
+    tm64 = base.double().requires_grad_(True)
+    cj64 = (cj[0].double(), cj[1].double()) + tuple(cj[2:])
+    cv64 = o64.jtmpn(*cj64, tm64)
+    R4 = projection(cv64.shape, 4)
+    (cv64 * R4.double()).sum().backward()
+    tm = base.cuda().requires_grad_(True)
+    cv = hip.jtmpn(*cj, tm)
+    (cv * R4.cuda()).sum().backward()
+    assert rel_err(cv.detach().cpu().numpy(), cv64.detach().numpy()) < 2e-6
+    ref = grads(o64.jtmpn)
+    for n, v in grads(hip.jtmpn).items():
+        assert fro_err(v, ref[n]) < RTOL, (n, fro_err(v, ref[n]))
+    # row 0 of tree_message is the constant zero padding message: the reference's gather adds
+    # every padding slot's gradient to it, the kernels skip padding slots, and GraphGRU's mask
+    # discards that row's gradient either way (fast_jtnn/jtnn_enc.py:108-109,126)
+    assert fro_err(tm.grad.cpu().numpy()[1:], tm64.grad.numpy()[1:]) < RTOL
+    assert float(tm.grad[0].abs().max()) == 0.0
 
 
 def test_inference_equals_training_forward_and_is_deterministic():
@@ -167,7 +236,10 @@ def test_edge_cases():
         assert rel_err(a.detach().cpu().numpy(), b.detach().numpy()) < RTOL
         a.sum().backward(); b.sum().backward()
         for (n, p), (_, q) in zip(hip.named_parameters(), ora.named_parameters()):
-            assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < 5e-4, (H, depth, n)
+            if q.grad is None:  # depth 1 never touches W_h
+                assert float(p.grad.abs().max()) == 0.0, n
+                continue
+            assert fro_err(p.grad.cpu().numpy(), q.grad.numpy()) < RTOL, (H, depth, n)
         # trees: one single-node tree and one two-node tree
         t1 = synthetic.Tree([synthetic.TreeNode(1, 2)], mols[0])
         n1, n2 = synthetic.TreeNode(1, 0), synthetic.TreeNode(2, 4)
@@ -185,7 +257,10 @@ def test_edge_cases():
         assert rel_err(ms.detach().cpu().numpy(), mso.detach().numpy()) < RTOL
         (tv.sum() + ms.sum()).backward(); (tvo.sum() + mso.sum()).backward()
         for (n, p), (_, q) in zip(hip_e.named_parameters(), ora_e.named_parameters()):
-            assert rel_err(p.grad.cpu().numpy(), q.grad.numpy()) < 5e-4, (H, depth, n)
+            if q.grad is None:
+                assert float(p.grad.abs().max()) == 0.0, n
+                continue
+            assert fro_err(p.grad.cpu().numpy(), q.grad.numpy()) < RTOL, (H, depth, n)
 
 
 def test_out_of_range_index_is_rejected_on_the_host():

@@ -15,12 +15,34 @@ def K():
     return _capi
 
 
+# Raw pointers cross the C ABI, so every device tensor must outlive the launch that reads it:
+# a temporary freed right after .data_ptr() can be handed to the next allocation and overwritten
+# before the kernel runs.  Helpers park their tensors here until the test ends.
+_KEEP = []
+
+
+@pytest.fixture(autouse=True)
+def _release_device_tensors():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+def keep(t):
+    _KEEP.append(t)
+    return t
+
+
 def dev_rows(x, ld):
     """numpy [n, H] -> padded device buffer [n, ld] with NaN-free garbage in the padding."""
     n, h = x.shape
     buf = torch.full((n, ld), 7.5, dtype=torch.float32, device="cuda")
-    buf[:, :h] = torch.from_numpy(x).cuda()
-    return buf
+    buf[:, :h] = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+    return keep(buf)
+
+
+def dev(x):
+    return keep(torch.from_numpy(np.ascontiguousarray(x)).cuda())
 
 
 @pytest.mark.parametrize("M,N,Kd", [(1, 450, 450), (129, 450, 450), (1000, 450, 450), (257, 96, 96),
@@ -38,12 +60,12 @@ def test_gemm_nt_plain(K, M, N, Kd):
             Ad, Wd = dev_rows(A, lda), dev_rows(W, lda)
             a_ld = w_ld = lda
         else:
-            Ad, Wd = torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda()
+            Ad, Wd = dev(A), dev(W)
             a_ld = w_ld = Kd
         C = torch.full((M, ldc), -3.0, device="cuda")
         pre = torch.full((M, ldc), -3.0, device="cuda")
         K.gemm_nt(Ad.data_ptr(), a_ld, Wd.data_ptr(), w_ld, C.data_ptr(), ldc, M, N, Kd,
-                  bias=torch.from_numpy(bias).cuda().data_ptr(), add=dev_rows(add, ldc).data_ptr(), ld_add=ldc,
+                  bias=dev(bias).data_ptr(), add=dev_rows(add, ldc).data_ptr(), ld_add=ldc,
                   act=K.ACT_RELU, pre_out=pre.data_ptr(), ld_pre=ldc)
         torch.cuda.synchronize()
         assert rel_err(pre[:, :N].cpu().numpy(), ref) < 2e-6
@@ -63,7 +85,7 @@ def test_gemm_nt_table_addend_and_activations(K):
     for act, fn in ((K.ACT_SIGMOID, lambda v: 1 / (1 + np.exp(-v))), (K.ACT_TANH, np.tanh), (K.ACT_NONE, lambda v: v)):
         C = torch.empty((M, ld), device="cuda")
         K.gemm_nt(dev_rows(A, ld).data_ptr(), ld, dev_rows(W, ld).data_ptr(), ld, C.data_ptr(), ld, M, N, Kd,
-                  add=dev_rows(tab, ld).data_ptr(), ld_add=ld, add_idx=torch.from_numpy(idx).cuda().data_ptr(),
+                  add=dev_rows(tab, ld).data_ptr(), ld_add=ld, add_idx=dev(idx).data_ptr(),
                   act=act)
         torch.cuda.synchronize()
         assert rel_err(C[:, :N].cpu().numpy(), fn(pre)) < 3e-6
@@ -85,7 +107,7 @@ def test_gemm_nt_gru_blend_and_mul_acc(K):
     P = torch.empty((M, ld), device="cuda")
     Hn = torch.empty((M, ld), device="cuda")
     K.gemm_nt(dev_rows(G, ld).data_ptr(), ld, dev_rows(W, ld).data_ptr(), ld, P.data_ptr(), ld, M, N, N,
-              add=dev_rows(tab, ld).data_ptr(), ld_add=ld, add_idx=torch.from_numpy(idx).cuda().data_ptr(),
+              add=dev_rows(tab, ld).data_ptr(), ld_add=ld, add_idx=dev(idx).data_ptr(),
               mode=K.EPI_GRU_BLEND, aux0=dev_rows(z, ld).data_ptr(), aux1=dev_rows(s, ld).data_ptr(),
               out2=Hn.data_ptr(), ld_aux=ld)
     torch.cuda.synchronize()
@@ -172,8 +194,8 @@ def test_csr_gather_sum_variants(K, H):
     for i in range(n_rows):
         for e in range(rp[i], rp[i + 1]):
             ref[i] += cat[col[e]]
-    rpd = torch.from_numpy(rp.astype(np.int32)).cuda()
-    cold = torch.from_numpy(col.astype(np.int32)).cuda()
+    rpd = dev(rp.astype(np.int32))
+    cold = dev(col.astype(np.int32))
     out = torch.full((n_rows, ld), 9.0, device="cuda")
     K.csr_gather_sum(out.data_ptr(), dev_rows(s0, ld).data_ptr(), n0, dev_rows(s1, ld).data_ptr(), rpd.data_ptr(),
                      cold.data_ptr(), n_rows, H, ld)
@@ -203,7 +225,7 @@ def test_segment_mean_and_backward_and_slab_sum(K):
     n = int(lens.sum())
     rows = rs.standard_normal((n, H)).astype(np.float32)
     seg = np.stack([starts, lens], 1).astype(np.int32)
-    segd = torch.from_numpy(seg).cuda()
+    segd = dev(seg)
     out = torch.empty((50, ld), device="cuda")
     K.segment_mean(out.data_ptr(), dev_rows(rows, ld).data_ptr(), segd.data_ptr(), 50, H, ld)
     ref = np.stack([rows[s:s + l].astype(np.float64).mean(0) for s, l in zip(starts, lens)])
@@ -214,7 +236,7 @@ def test_segment_mean_and_backward_and_slab_sum(K):
     seg_of[5] = -1
     drows = torch.empty((n, ld), device="cuda")
     K.segment_mean_bwd(drows.data_ptr(), dev_rows(dout, ld).data_ptr(), dev_rows(rows, ld).data_ptr(),
-                       segd.data_ptr(), torch.from_numpy(seg_of).cuda().data_ptr(), n, H, ld)
+                       segd.data_ptr(), dev(seg_of).data_ptr(), n, H, ld)
     torch.cuda.synchronize()
     want = dout[np.maximum(seg_of, 0)] / lens[np.maximum(seg_of, 0)][:, None] * (rows > 0)
     want[5] = 0
@@ -249,7 +271,7 @@ def test_gru_kernels(K):
             r = sig(Pr[wid[m]].astype(np.float64) + Uh[j])
             s_ref[m] += h[j]; g_ref[m] += r * h[j]; t_ref[m] += r * (1 - r) * h[j]
     dv = lambda x: dev_rows(x.astype(np.float32), ld)  # noqa: E731
-    i32 = lambda x: torch.from_numpy(np.ascontiguousarray(x, dtype=np.int32)).cuda()  # noqa: E731
+    i32 = lambda x: dev(np.asarray(x, dtype=np.int32))  # noqa: E731
     hd, Ud, Prd, widd, rpd, cold = dv(h), dv(Uh), dv(Pr), i32(wid), i32(rp), i32(col)
     s, g, t = (torch.empty((NM, ld), device="cuda") for _ in range(3))
     K.gru_gate_gather(hd.data_ptr(), Ud.data_ptr(), Prd.data_ptr(), widd.data_ptr(), rpd.data_ptr(),
@@ -311,7 +333,7 @@ def test_row_dot(K):
     c = rs.standard_normal((NC, H)).astype(np.float32)
     own = rs.randint(0, B, size=NC).astype(np.int32)
     sc = torch.empty(NC, device="cuda")
-    K.row_dot(sc.data_ptr(), dev_rows(q, ld).data_ptr(), torch.from_numpy(own).cuda().data_ptr(),
+    K.row_dot(sc.data_ptr(), dev_rows(q, ld).data_ptr(), dev(own).data_ptr(),
               dev_rows(c, ld).data_ptr(), NC, H, ld)
     torch.cuda.synchronize()
     assert rel_err(sc.cpu().numpy(), (q[own].astype(np.float64) * c).sum(1)) < 2e-6
