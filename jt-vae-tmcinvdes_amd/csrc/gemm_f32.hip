@@ -11,9 +11,11 @@
 //                                                         into slabs summed in fixed order
 //
 // N = K = 450 on the hot calls, M = 4e4..9e5.  Tiles are cut for that: the NT block
-// is 128 rows x 160 columns (3 column blocks cover 480 >= 450: 6 % padding waste,
-// against 14 % for 128/256-wide tiles), one wave owns 32 rows x 160 columns = five
-// 32x32 accumulators.
+// is 128 rows x 96 columns (5 column blocks cover 480 >= 450: 6 % padding waste,
+// against 14 % for 128/256-wide tiles); one wave owns 32 rows x 96 columns = three
+// 32x32 accumulators, which keeps the kernel near 128 VGPRs so that four blocks
+// (four waves per SIMD) are resident per CU: the matrix pipe of a SIMD then always has
+// a wave with MFMAs to issue while the others sit in a barrier or stage the next tile.
 #include "jtvae_common.h"
 #include "../../include/jtvae_hip.h"
 
@@ -24,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int NT_BM = 128;
-constexpr int NT_BN = 160;
+constexpr int NT_BN = 96;
 constexpr int NT_BK = 32;
 constexpr int NT_LDS = 36;  // floats per LDS row: 32 + 4 -> ds_read_b128 of 16 rows hits 16 distinct 16-B slots
 constexpr int NT_NT = NT_BN / 32;  // accumulators per wave
@@ -49,25 +51,30 @@ struct NtArgs {
   jtvae_epilogue_t e;
 };
 
+// Tile loads are split in two so that they stay in flight behind the MFMAs of the current
+// tile: load4_raw issues an unconditional load from a clamped (always valid) address, mask4
+// zeroes what lies outside the matrix once the value is consumed.  A bounds check wrapped around
+// the load itself makes the compiler wait for each load separately, right where it is issued.
 template <bool VEC>
-__device__ __forceinline__ float4 load4(const float* base, int ld, int row, int row_end, int k, int K) {
-  float4 v = f4zero();
-  if (row < row_end && k < K) {
-    const float* p = base + (size_t)row * ld + k;
-    if (VEC) {
-      v = *reinterpret_cast<const float4*>(p);
-      if (k + 3 >= K) {
-        if (k + 1 >= K) v.y = 0.f;
-        if (k + 2 >= K) v.z = 0.f;
-        v.w = 0.f;
-      }
-    } else {
-      v.x = p[0];
-      if (k + 1 < K) v.y = p[1];
-      if (k + 2 < K) v.z = p[2];
-      if (k + 3 < K) v.w = p[3];
-    }
-  }
+__device__ __forceinline__ float4 load4_raw(const float* base, int ld, int row, int row_end, int k, int K) {
+  const int rc = min(row, row_end - 1);
+  const int kc = k < K ? k : 0;
+  const float* p = base + (size_t)rc * ld + kc;
+  if (VEC) return *reinterpret_cast<const float4*>(p);  // k % 4 == 0 and ld % 4 == 0: inside the row
+  const int last = K - 1 - kc;
+  float4 v;
+  v.x = p[0];
+  v.y = p[min(1, last)];
+  v.z = p[min(2, last)];
+  v.w = p[min(3, last)];
+  return v;
+}
+__device__ __forceinline__ float4 mask4(float4 v, int row, int row_end, int k, int K) {
+  const bool ok = row < row_end;
+  v.x = (ok && k + 0 < K) ? v.x : 0.f;
+  v.y = (ok && k + 1 < K) ? v.y : 0.f;
+  v.z = (ok && k + 2 < K) ? v.z : 0.f;
+  v.w = (ok && k + 3 < K) ? v.w : 0.f;
   return v;
 }
 
@@ -81,7 +88,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs a) {
+__global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   __shared__ __attribute__((aligned(16))) float As[NT_BM * NT_LDS];
   __shared__ __attribute__((aligned(16))) float Bs[NT_BN * NT_LDS];
 
@@ -100,24 +107,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs a) {
 
   const int srow = tid >> 3;  // staging: 8 threads (8 x float4 = 32 floats) per tile row
   const int sc4 = tid & 7;
-  float4 ra[4], rb[5];
+  float4 ra[NT_BM / 32], rb[NT_BN / 32];
 
+  const int n_rows_b = min(a.N, n0 + NT_BN);  // W rows this block may touch
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = load4<VEC>(a.A, a.lda, m0 + srow + 32 * i, a.M, k0 + 4 * sc4, a.K);
+    for (int i = 0; i < 4; ++i) ra[i] = load4_raw<VEC>(a.A, a.lda, m0 + srow + 32 * i, a.M, k0 + 4 * sc4, a.K);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) rb[i] = load4<VEC>(a.W, a.ldw, n0 + srow + 32 * i, a.N, k0 + 4 * sc4, a.K);
+    for (int i = 0; i < NT_BN / 32; ++i) rb[i] = load4_raw<VEC>(a.W, a.ldw, n0 + srow + 32 * i, n_rows_b, k0 + 4 * sc4, a.K);
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&As[(srow + 32 * i) * NT_LDS + 4 * sc4]) = ra[i];
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(&As[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
+          mask4(ra[i], m0 + srow + 32 * i, a.M, k0 + 4 * sc4, a.K);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * NT_LDS + 4 * sc4]) = rb[i];
+    for (int i = 0; i < NT_BN / 32; ++i)
+      *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
+          mask4(rb[i], n0 + srow + 32 * i, a.N, k0 + 4 * sc4, a.K);
   };
 
   const int nk = (a.K + NT_BK - 1) / NT_BK;
   load_tiles(0);
-  store_tiles();
+  store_tiles(0);
   __syncthreads();
 
   // operand fragment addresses: lane l supplies row (l & 31); its half (l >> 5) picks which
@@ -129,8 +141,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs a) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) load_tiles((kt + 1) * NT_BK);  // in flight during the MFMAs below
+    // the last tile of K = 450 holds two valid columns: skip its empty 8-column groups
+    const int kk_end = min(NT_BK / 8, (a.K - kt * NT_BK + 7) >> 3);
 #pragma unroll
     for (int kk = 0; kk < NT_BK / 8; ++kk) {
+      if (kk >= kk_end) break;
       float4 av = *reinterpret_cast<const float4*>(a_frag + 8 * kk);
       float4 bv[NT_NT];
 #pragma unroll
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs a) {
     }
     __syncthreads();
     if (more) {
-      store_tiles();
+      store_tiles((kt + 1) * NT_BK);
       __syncthreads();
     }
   }
@@ -236,30 +251,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int idx = tid + 256 * i;  // 32 rows x 32 float4
-      rx[i] = load4<VEC>(a.X, a.ldx, mb + (idx >> 5), m_end, n0 + 4 * (idx & 31), a.N);
+      rx[i] = load4_raw<VEC>(a.X, a.ldx, mb + (idx >> 5), m_end, n0 + 4 * (idx & 31), a.N);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       int idx = tid + 256 * i;  // 32 rows x 24 float4
-      ry[i] = load4<VEC>(a.Y, a.ldy, mb + idx / 24, m_end, k0 + 4 * (idx % 24), a.K);
+      ry[i] = load4_raw<VEC>(a.Y, a.ldy, mb + idx / 24, m_end, k0 + 4 * (idx % 24), a.K);
     }
   };
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int idx = tid + 256 * i;
-      *reinterpret_cast<float4*>(&Xs[(idx >> 5) * TN_BN + 4 * (idx & 31)]) = rx[i];
+      *reinterpret_cast<float4*>(&Xs[(idx >> 5) * TN_BN + 4 * (idx & 31)]) =
+          mask4(rx[i], mb + (idx >> 5), m_end, n0 + 4 * (idx & 31), a.N);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       int idx = tid + 256 * i;
-      *reinterpret_cast<float4*>(&Ys[(idx / 24) * TN_BKK + 4 * (idx % 24)]) = ry[i];
+      *reinterpret_cast<float4*>(&Ys[(idx / 24) * TN_BKK + 4 * (idx % 24)]) =
+          mask4(ry[i], mb + idx / 24, m_end, k0 + 4 * (idx % 24), a.K);
     }
   };
 
   if (m_beg < m_end) {
     load_tiles(m_beg);
-    store_tiles();
+    store_tiles(m_beg);
     __syncthreads();
     const float* xf = &Xs[(lane >> 5) * TN_BN + wave * 32 + (lane & 31)];
     const float* yf = &Ys[(lane >> 5) * TN_BKK + (lane & 31)];
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
       }
       __syncthreads();
       if (more) {
-        store_tiles();
+        store_tiles(mb + TN_BM);
         __syncthreads();
       }
     }

@@ -3,12 +3,20 @@
 There is no fallback: if the library is missing or a symbol is absent the import
 fails, and every call raises on a non-zero return code.  PyTorch is used only to
 own device memory and to name the stream; tensors cross the boundary as raw
-device pointers.
+device pointers, so CALLERS MUST KEEP EVERY TENSOR ALIVE UNTIL THE LAUNCH THAT
+READS IT HAS BEEN ENQUEUED (a temporary freed right after ``.data_ptr()`` can be
+handed to the next allocation and overwritten first).
+
+``KernelTimer`` is the measurement hook: inside ``with KernelTimer() as t:`` every
+call is bracketed by HIP events on the launch stream and tagged with its
+algorithmic work (bytes for the row kernels, flops for the GEMMs), which is what
+bench.py turns into achieved GB/s and TFLOP/s per kernel.
 """
 from __future__ import annotations
 
 import ctypes as C
 import os
+from collections import OrderedDict
 
 import torch
 
@@ -115,76 +123,140 @@ def rows(n: int, ld: int, device, zero: bool = False) -> torch.Tensor:
     return f((max(n, 0), ld), dtype=torch.float32, device=device)
 
 
+# ---- measurement hook ------------------------------------------------------------------------
+
+
+class KernelTimer:
+    """Collects (kernel, algorithmic bytes, algorithmic flops, HIP-event pair) per C-ABI call."""
+
+    active = None
+
+    def __init__(self):
+        self.records = []
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+        return False
+
+    def summary(self):
+        """kernel -> dict(launches, ms, bytes, flops); synchronises once."""
+        torch.cuda.synchronize()
+        out = OrderedDict()
+        for name, nbytes, flops, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0, flops=0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nbytes
+            d["flops"] += flops
+        return out
+
+
+def _run(name, fn, args, nbytes=0, flops=0):
+    t = KernelTimer.active
+    if t is None:
+        check(fn(*args), name)
+        return
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    t.records.append((name, int(nbytes), int(flops), e0, e1))
+    check(rc, name)
+
+
 # ---- thin call wrappers (sizes are taken from explicit arguments, never guessed) -----------
+# Tensor arguments are raw device pointers (ints) or None.  `nnz` arguments exist only to price
+# the call for KernelTimer (rows read = nnz); None leaves the gather unpriced.
 
 
 def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0, add_idx=None,
             act=ACT_NONE, pre_out=None, ld_pre=0, mode=EPI_PLAIN, aux0=None, aux1=None, out2=None,
             ld_aux=0):
-    """All tensor arguments are raw device pointers (ints) or None."""
     e = Epilogue(bias, add, ld_add, add_idx, act, pre_out, ld_pre, mode, aux0, aux1, out2, ld_aux)
-    check(lib.jtvae_gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()), "jtvae_gemm_nt")
+    extra = (1 if add else 0) + (1 if pre_out else 0) + {EPI_PLAIN: 0, EPI_GRU_BLEND: 3, EPI_MUL_ACC: 3}[mode]
+    _run("gemm_nt", lib.jtvae_gemm_nt, (A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()),
+         nbytes=4 * (M * K + N * K + M * N * (1 + extra)), flops=2 * M * N * K)
 
 
 def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device):
     nbytes = lib.jtvae_gemm_tn_workspace_bytes(M, N, K)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-    check(lib.jtvae_gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, int(accumulate), ws.data_ptr(), nbytes,
-                            stream_ptr()), "jtvae_gemm_tn")
+    _run("gemm_tn", lib.jtvae_gemm_tn, (X, ldx, Y, ldy, dW, lddw, M, N, K, int(accumulate), ws.data_ptr(), nbytes,
+                                        stream_ptr()), nbytes=4 * (M * N + M * K + N * K), flops=2 * M * N * K)
 
 
 def colsum(X, ldx, out, M, N, accumulate, device):
     nbytes = lib.jtvae_colsum_workspace_bytes(M, N)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-    check(lib.jtvae_colsum(X, ldx, out, M, N, int(accumulate), ws.data_ptr(), nbytes, stream_ptr()),
-          "jtvae_colsum")
+    _run("colsum", lib.jtvae_colsum, (X, ldx, out, M, N, int(accumulate), ws.data_ptr(), nbytes, stream_ptr()),
+         nbytes=4 * (M * N + N))
 
 
 def transpose(src, ld_src, dst, ld_dst, nrows, ncols):
-    check(lib.jtvae_transpose(src, ld_src, dst, ld_dst, nrows, ncols, stream_ptr()), "jtvae_transpose")
+    _run("transpose", lib.jtvae_transpose, (src, ld_src, dst, ld_dst, nrows, ncols, stream_ptr()),
+         nbytes=8 * nrows * ncols)
 
 
 def copy_rows(src, ld_src, dst, ld_dst, nrows, ncols):
-    check(lib.jtvae_copy_rows(src, ld_src, dst, ld_dst, nrows, ncols, stream_ptr()), "jtvae_copy_rows")
+    _run("copy_rows", lib.jtvae_copy_rows, (src, ld_src, dst, ld_dst, nrows, ncols, stream_ptr()),
+         nbytes=8 * nrows * ncols)
 
 
 def csr_gather_sum(out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask=None, accumulate=False,
-                   acc2=None):
-    check(lib.jtvae_csr_gather_sum(out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask,
-                                   int(accumulate), acc2, stream_ptr()), "jtvae_csr_gather_sum")
+                   acc2=None, nnz=None):
+    row_b = 4 * H
+    extra = (1 if relu_mask else 0) + (1 if accumulate else 0) + (2 if acc2 else 0)
+    nbytes = 0 if nnz is None else (nnz + n_rows * (1 + extra)) * row_b + 4 * (n_rows + 1 + nnz)
+    _run("csr_gather_sum", lib.jtvae_csr_gather_sum,
+         (out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask, int(accumulate), acc2, stream_ptr()),
+         nbytes=nbytes)
 
 
 def slab_sum(out, X, n_slabs, slab_stride, n_rows, H, ld):
-    check(lib.jtvae_slab_sum(out, X, n_slabs, slab_stride, n_rows, H, ld, stream_ptr()), "jtvae_slab_sum")
+    _run("slab_sum", lib.jtvae_slab_sum, (out, X, n_slabs, slab_stride, n_rows, H, ld, stream_ptr()),
+         nbytes=4 * H * n_rows * (n_slabs + 1))
 
 
-def segment_mean(out, rows_, seg, n_seg, H, ld):
-    check(lib.jtvae_segment_mean(out, rows_, seg, n_seg, H, ld, stream_ptr()), "jtvae_segment_mean")
+def segment_mean(out, rows_, seg, n_seg, H, ld, n_rows=None):
+    _run("segment_mean", lib.jtvae_segment_mean, (out, rows_, seg, n_seg, H, ld, stream_ptr()),
+         nbytes=0 if n_rows is None else 4 * H * (n_rows + n_seg) + 8 * n_seg)
 
 
-def segment_mean_bwd(drows, dout, act, seg, seg_of, n_rows, H, ld):
-    check(lib.jtvae_segment_mean_bwd(drows, dout, act, seg, seg_of, n_rows, H, ld, stream_ptr()),
-          "jtvae_segment_mean_bwd")
+def segment_mean_bwd(drows, dout, act, seg, seg_of, n_rows, H, ld, n_seg=0):
+    _run("segment_mean_bwd", lib.jtvae_segment_mean_bwd,
+         (drows, dout, act, seg, seg_of, n_rows, H, ld, stream_ptr()),
+         nbytes=4 * H * (2 * n_rows + n_seg) + 4 * n_rows)
 
 
 def gru_iter0(Pz, Ph, wid, z, p, h1, n_mess, H, ld):
-    check(lib.jtvae_gru_iter0(Pz, Ph, wid, z, p, h1, n_mess, H, ld, stream_ptr()), "jtvae_gru_iter0")
+    _run("gru_iter0", lib.jtvae_gru_iter0, (Pz, Ph, wid, z, p, h1, n_mess, H, ld, stream_ptr()),
+         nbytes=4 * H * n_mess * 5 + 4 * n_mess)
 
 
-def gru_gate_gather(h, Uh, Pr, wid, rowptr, col, s, g, t, n_mess, H, ld):
-    check(lib.jtvae_gru_gate_gather(h, Uh, Pr, wid, rowptr, col, s, g, t, n_mess, H, ld, stream_ptr()),
-          "jtvae_gru_gate_gather")
+def gru_gate_gather(h, Uh, Pr, wid, rowptr, col, s, g, t, n_mess, H, ld, nnz=None):
+    # rows: h and Uh per edge, the W_r x table row per message, s / g (/ t) written
+    nbytes = 0 if nnz is None else 4 * H * (2 * nnz + n_mess * (1 + (3 if t else 2))) + 4 * (2 * n_mess + 1 + nnz)
+    _run("gru_gate_gather", lib.jtvae_gru_gate_gather,
+         (h, Uh, Pr, wid, rowptr, col, s, g, t, n_mess, H, ld, stream_ptr()), nbytes=nbytes)
 
 
 def gru_bwd_pointwise(dh, z, p, s, dzpre, dppre, ds, n_mess, H, ld):
-    check(lib.jtvae_gru_bwd_pointwise(dh, z, p, s, dzpre, dppre, ds, n_mess, H, ld, stream_ptr()),
-          "jtvae_gru_bwd_pointwise")
+    _run("gru_bwd_pointwise", lib.jtvae_gru_bwd_pointwise,
+         (dh, z, p, s, dzpre, dppre, ds, n_mess, H, ld, stream_ptr()), nbytes=4 * H * n_mess * 7)
 
 
-def gru_bwd_gather(h, Uh, Pr, wid, dg, ds, trowptr, tcol, dUh, dhdir, n_mess, H, ld):
-    check(lib.jtvae_gru_bwd_gather(h, Uh, Pr, wid, dg, ds, trowptr, tcol, dUh, dhdir, n_mess, H, ld,
-                                   stream_ptr()), "jtvae_gru_bwd_gather")
+def gru_bwd_gather(h, Uh, Pr, wid, dg, ds, trowptr, tcol, dUh, dhdir, n_mess, H, ld, nnz=None):
+    # rows: h, Uh read and dUh, dhdir written per message; table row, dg, ds read per edge
+    nbytes = 0 if nnz is None else 4 * H * (4 * n_mess + 3 * nnz) + 4 * (n_mess + 1 + 2 * nnz)
+    _run("gru_bwd_gather", lib.jtvae_gru_bwd_gather,
+         (h, Uh, Pr, wid, dg, ds, trowptr, tcol, dUh, dhdir, n_mess, H, ld, stream_ptr()), nbytes=nbytes)
 
 
 def row_dot(score, q, owner, cand, n_cand, H, ld):
-    check(lib.jtvae_row_dot(score, q, owner, cand, n_cand, H, ld, stream_ptr()), "jtvae_row_dot")
+    _run("row_dot", lib.jtvae_row_dot, (score, q, owner, cand, n_cand, H, ld, stream_ptr()),
+         nbytes=4 * H * 2 * n_cand + 8 * n_cand)

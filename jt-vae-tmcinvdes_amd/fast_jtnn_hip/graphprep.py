@@ -149,6 +149,8 @@ class GraphMPNPrep:
     seg: torch.Tensor  # int32 [B, 2]
     seg_of: torch.Tensor  # int32 [NA]
     n_seg: int
+    b_tree_nnz: int = 0  # bgraph / agraph entries that point at tree-message rows
+    a_tree_nnz: int = 0
 
 
 def prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
@@ -177,6 +179,7 @@ def prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
         seg=_dev_i32(seg.reshape(-1), device).view(-1, 2) if seg.size else torch.zeros((0, 2), dtype=torch.int32, device=device),
         seg_of=_dev_i32(seg_of, device) if na else torch.zeros(1, dtype=torch.int32, device=device),
         n_seg=int(seg.shape[0]),
+        b_tree_nnz=int((b_col < n_tree).sum()), a_tree_nnz=int((a_col < n_tree).sum()),
     )
 
 

@@ -75,7 +75,7 @@ class _TreeGRU:
             K.gemm_nt(h.data_ptr(), ld, Ur.data_ptr(), ld, us[i].data_ptr(), ld, NM, H, H, bias=bu.data_ptr())
             K.gru_gate_gather(h.data_ptr(), us[i].data_ptr(), Pr.data_ptr(), wid_p, mcsr.rowptr.data_ptr(),
                               mcsr.col.data_ptr(), ss[i].data_ptr(), gs[i].data_ptr(),
-                              ts[i].data_ptr() if train else None, NM, H, ld)
+                              ts[i].data_ptr() if train else None, NM, H, ld, nnz=mcsr.nnz)
             # z = sigmoid(W_z[:, H:] s + Pz[wid])
             K.gemm_nt(ss[i].data_ptr(), ld, Wzh.data_ptr(), ld, zs[i].data_ptr(), ld, NM, H, H,
                       add=Pz.data_ptr(), ld_add=ld, add_idx=wid_p, act=K.ACT_SIGMOID)
@@ -110,7 +110,7 @@ class _TreeGRU:
                       mode=K.EPI_MUL_ACC, aux0=ts[t].data_ptr(), out2=a_r.data_ptr(), ld_aux=ld)
             K.gru_bwd_gather(hs[t].data_ptr(), us[t].data_ptr(), Pr.data_ptr(), wid_p, dg.data_ptr(),
                              ds.data_ptr(), mcsr_t.rowptr.data_ptr(), mcsr_t.col.data_ptr(),
-                             du[t].data_ptr(), dhdir.data_ptr(), NM, H, ld)
+                             du[t].data_ptr(), dhdir.data_ptr(), NM, H, ld, nnz=mcsr_t.nnz)
             # dh_t = dUh U_r + direct part
             K.gemm_nt(du[t].data_ptr(), ld, UrT.data_ptr(), ld, dh.data_ptr(), ld, NM, H, H,
                       add=dhdir.data_ptr(), ld_add=ld)
@@ -124,10 +124,10 @@ def _keyed_sum(src, pieces, key_csr, n_keys, H, ld, dev):
     """out[k] = sum of src rows whose key is k (fixed order: pieces, then pieces of a key)."""
     part = K.rows(pieces.n_rows, ld, dev)
     K.csr_gather_sum(part.data_ptr(), src.data_ptr(), src.shape[0], None, pieces.rowptr.data_ptr(),
-                     pieces.col.data_ptr(), pieces.n_rows, H, ld)
+                     pieces.col.data_ptr(), pieces.n_rows, H, ld, nnz=pieces.nnz)
     out = K.rows(n_keys, ld, dev)
     K.csr_gather_sum(out.data_ptr(), part.data_ptr(), pieces.n_rows, None, key_csr.rowptr.data_ptr(),
-                     key_csr.col.data_ptr(), n_keys, H, ld)
+                     key_csr.col.data_ptr(), n_keys, H, ld, nnz=key_csr.nnz)
     return out
 
 
@@ -148,7 +148,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         E_p = as_row_buffer(E, H, ld)
         Eu = K.rows(NW, ld, dev)
         K.csr_gather_sum(Eu.data_ptr(), E_p.data_ptr(), E.shape[0], None, P.word_csr.rowptr.data_ptr(),
-                         P.word_csr.col.data_ptr(), NW, H, ld)
+                         P.word_csr.col.data_ptr(), NW, H, ld, nnz=NW)
         Wzx, Wzh = _pack_weight(Wz, 0, H), _pack_weight(Wz, H, H)
         Whx, Whh = _pack_weight(Wh, 0, H), _pack_weight(Wh, H, H)
         Wox, Woh = _pack_weight(Wout, 0, H), _pack_weight(Wout, H, H)
@@ -165,7 +165,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         # output stage on the root nodes only                             (jtnn_enc.py:31-41)
         nsum = K.rows(B, ld, dev)
         K.csr_gather_sum(nsum.data_ptr(), h.data_ptr(), NM, None, P.rcsr.rowptr.data_ptr(),
-                         P.rcsr.col.data_ptr(), B, H, ld)
+                         P.rcsr.col.data_ptr(), B, H, ld, nnz=P.rcsr.nnz)
         tv = K.rows(B, ld, dev)
         K.gemm_nt(nsum.data_ptr(), ld, Woh.data_ptr(), ld, tv.data_ptr(), ld, B, H, H, add=Po.data_ptr(),
                   ld_add=ld, add_idx=P.wid_root.data_ptr(), act=K.ACT_RELU)
@@ -200,7 +200,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         else:
             dtv_p = as_row_buffer(dtv, H, ld)
             K.csr_gather_sum(dpre_root.data_ptr(), dtv_p.data_ptr(), B, None, P.ident.rowptr.data_ptr(),
-                             P.ident.col.data_ptr(), B, H, ld, relu_mask=tv.data_ptr())
+                             P.ident.col.data_ptr(), B, H, ld, relu_mask=tv.data_ptr(), nnz=B)
         K.gemm_tn(dpre_root.data_ptr(), ld, nsum.data_ptr(), ld, K.ptr(dWout, H), 2 * H, B, H, H, False, dev)
         dnsum = K.rows(B, ld, dev)
         K.gemm_nt(dpre_root.data_ptr(), ld, WohT.data_ptr(), ld, dnsum.data_ptr(), ld, B, H, H)
@@ -209,7 +209,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
             K.copy_rows(dmess.data_ptr() if dmess.stride(1) == 1 else dmess.contiguous().data_ptr(),
                         dmess.stride(0) if dmess.stride(1) == 1 else H, dh.data_ptr(), ld, NM, H)
         K.csr_gather_sum(dh.data_ptr(), dnsum.data_ptr(), B, None, P.rcsr_t.rowptr.data_ptr(),
-                         P.rcsr_t.col.data_ptr(), NM, H, ld, accumulate=dmess is not None)
+                         P.rcsr_t.col.data_ptr(), NM, H, ld, accumulate=dmess is not None, nnz=P.rcsr_t.nnz)
 
         WzhT, WhhT, UrT = _pack_weight_t(Wz, H, H), _pack_weight_t(Wh, H, H), _pack_weight_t(Ur_w, 0, H)
         dz, dp, du, a_r = _TreeGRU.backward(dh, T, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT, WhhT, UrT)
@@ -252,7 +252,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
             first = False
         dE_p = K.rows(V, ld, dev)
         K.csr_gather_sum(dE_p.data_ptr(), dEu.data_ptr(), NW, None, P.word_csr_t.rowptr.data_ptr(),
-                         P.word_csr_t.col.data_ptr(), V, H, ld)
+                         P.word_csr_t.col.data_ptr(), V, H, ld, nnz=NW)
         dE = torch.empty((V, H), dtype=torch.float32, device=dev)
         K.copy_rows(dE_p.data_ptr(), ld, dE.data_ptr(), H, V, H)
         return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None

@@ -108,10 +108,10 @@ class _GraphMPNFunction(torch.autograd.Function):
         def gather(out, msg, csr, n_rows):
             if TM:
                 K.csr_gather_sum(out.data_ptr(), src0, TM, msg.data_ptr(), csr.rowptr.data_ptr(),
-                                 csr.col.data_ptr(), n_rows, H, ld)
+                                 csr.col.data_ptr(), n_rows, H, ld, nnz=csr.nnz)
             else:
                 K.csr_gather_sum(out.data_ptr(), msg.data_ptr(), NB, None, csr.rowptr.data_ptr(),
-                                 csr.col.data_ptr(), n_rows, H, ld)
+                                 csr.col.data_ptr(), n_rows, H, ld, nnz=csr.nnz)
 
         binput = K.rows(NB, ld, dev)
         msgs = [K.rows(NB, ld, dev)]
@@ -138,7 +138,7 @@ class _GraphMPNFunction(torch.autograd.Function):
         K.gemm_nt(anei.data_ptr(), ld, Woh.data_ptr(), ld, ah.data_ptr(), ld, NA, H, H,
                   add=ah.data_ptr(), ld_add=ld, act=K.ACT_RELU)
         out = K.rows(P.n_seg, ld, dev)  # mpn.py:102-107
-        K.segment_mean(out.data_ptr(), ah.data_ptr(), P.seg.data_ptr(), P.n_seg, H, ld)
+        K.segment_mean(out.data_ptr(), ah.data_ptr(), P.seg.data_ptr(), P.n_seg, H, ld, n_rows=NA)
 
         if train:
             ctx.prep, ctx.depth, ctx.H, ctx.ld = P, depth, H, ld
@@ -167,7 +167,7 @@ class _GraphMPNFunction(torch.autograd.Function):
         # through the mean readout and the ReLU of W_o                    (mpn.py:99-105)
         dpre_o = K.rows(NA, ld, dev)
         K.segment_mean_bwd(dpre_o.data_ptr(), dout_p.data_ptr(), ah.data_ptr(), P.seg.data_ptr(),
-                           P.seg_of.data_ptr(), NA, H, ld)
+                           P.seg_of.data_ptr(), NA, H, ld, n_seg=P.n_seg)
         w_in = ctx.W_o_shape[1]
         K.gemm_tn(dpre_o.data_ptr(), ld, P.fatoms.data_ptr(), P.fatoms.stride(0), dW_o.data_ptr(), w_in,
                   NA, H, fa_dim, False, dev)
@@ -176,26 +176,26 @@ class _GraphMPNFunction(torch.autograd.Function):
         danei = K.rows(NA, ld, dev)
         K.gemm_nt(dpre_o.data_ptr(), ld, WohT.data_ptr(), ld, danei.data_ptr(), ld, NA, H, H)
 
-        def gather_t(src, csr_t, mask, dbin, first_tree):
+        def gather_t(src, csr_t, tree_nnz, mask, dbin, first_tree):
             """Transposed gather of `src` rows into (tree rows | bond rows)."""
             dpre = K.rows(NB, ld, dev)
             K.csr_gather_sum(dpre.data_ptr(), src.data_ptr(), src.shape[0], None,
                              K.ptr(csr_t.rowptr, TM), csr_t.col.data_ptr(), NB, H, ld,
-                             relu_mask=mask.data_ptr(), acc2=dbin.data_ptr())
+                             relu_mask=mask.data_ptr(), acc2=dbin.data_ptr(), nnz=csr_t.nnz - tree_nnz)
             if TM:
                 K.csr_gather_sum(dtree.data_ptr(), src.data_ptr(), src.shape[0], None,
                                  csr_t.rowptr.data_ptr(), csr_t.col.data_ptr(), TM, H, ld,
-                                 accumulate=not first_tree)
+                                 accumulate=not first_tree, nnz=tree_nnz)
             return dpre
 
         dbinput = K.rows(NB, ld, dev, zero=True)
-        dpre = gather_t(danei, P.acsr_t, msgs[-1], dbinput, True)
+        dpre = gather_t(danei, P.acsr_t, P.a_tree_nnz, msgs[-1], dbinput, True)
         for i in range(depth - 1, 0, -1):  # message i = relu(binput + W_h nei_i)
             nei = neis[i - 1]
             K.gemm_tn(dpre.data_ptr(), ld, nei.data_ptr(), ld, dW_h.data_ptr(), H, NB, H, H, i != depth - 1, dev)
             dnei = K.rows(NB, ld, dev)
             K.gemm_nt(dpre.data_ptr(), ld, WhT.data_ptr(), ld, dnei.data_ptr(), ld, NB, H, H)
-            dpre = gather_t(dnei, P.bcsr_t, msgs[i - 1], dbinput, False)
+            dpre = gather_t(dnei, P.bcsr_t, P.b_tree_nnz, msgs[i - 1], dbinput, False)
         if depth == 1:
             dW_h.zero_()
         K.gemm_tn(dbinput.data_ptr(), ld, P.fbonds.data_ptr(), P.fbonds.stride(0), dW_i.data_ptr(),

@@ -1,0 +1,112 @@
+"""Molecule-batch data parallelism: one process per GPU, RCCL over xGMI.
+
+Molecules never interact inside the encoder (all index tables are batch-local
+concatenations, fast_jtnn/mpn.py:129-143, fast_jtnn/datautils.py:166-172), so a
+global batch is cut by molecule *before* tensorization and each rank builds and
+encodes its own shard.  The only exchange step of a training step is one
+all-reduce of the gradients, done on ONE flat fp32 bucket (about 20 MB for the
+whole model: a single ring pass per step; many small per-tensor collectives
+would be latency-bound on point-to-point xGMI links).  Bulk encoding has no
+exchange step at all.
+
+Losses in the reference are normalised by the local batch size
+(fast_jtnn/jtnn_vae.py:74,137), so with equal shards the average of the shard
+gradients equals the gradient of the concatenated batch.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def dist_env() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the launcher's environment; (0, 0, 1) when absent."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init_process_group(backend: str = None) -> Tuple[int, int, int]:
+    rank, local_rank, world = dist_env()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, near-equal split: the first ``n_items % world`` ranks get one extra item."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank %d of world %d" % (rank, world))
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_by_cost(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Balanced split of items with unequal cost (e.g. bonds + 20 x tree messages per molecule):
+    largest first onto the currently lightest rank.  Deterministic for a given input."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += costs[i]
+    for lst in out:
+        lst.sort()
+    return out
+
+
+class FlatGradBucket:
+    """All gradients of a module as views into one contiguous buffer.
+
+    ``zero()`` before backward, ``all_reduce_mean()`` after it.  Autograd adds into
+    the views, so no gather/scatter copies surround the collective.
+    """
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self) -> None:
+        self.flat.zero_()
+        for p in self.params:  # a caller may have replaced .grad (optimizer.zero_grad(set_to_none=True))
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
+                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
+                raise RuntimeError("a parameter's .grad no longer lives in the bucket; use bucket.zero() "
+                                   "instead of zero_grad(set_to_none=True)")
+
+    def all_reduce_mean(self) -> None:
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(dist.get_world_size())
+
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+
+def all_ranks_ok(ok: bool, device=None) -> bool:
+    """Skip-bad-batch semantics of the reference trainer (fast_molvae/vae_train.py:99-108) under
+    data parallelism: a step is skipped on every rank if it failed on any."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return ok
+    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    return int(flag.item()) == 0
