@@ -58,7 +58,8 @@ typedef struct jtvae_epilogue {
   const float* bias;      /* [N] added to every row, or NULL                               */
   const float* add;       /* addend rows, or NULL; may alias C (in-place accumulate)       */
   int32_t ld_add;
-  const int32_t* add_idx; /* NULL: addend row = m; else addend row = add_idx[m] (table)    */
+  const int32_t* add_idx; /* NULL: addend row = r; else addend row = add_idx[r] (table),   */
+                          /* r = id of the output row (see c_rows)                         */
   int32_t act;            /* JTVAE_ACT_*  (PLAIN mode only)                                */
   float* pre_out;         /* PLAIN: optional copy of the pre-activation value, or NULL     */
   int32_t ld_pre;
@@ -67,6 +68,13 @@ typedef struct jtvae_epilogue {
   const float* aux1;      /* GRU_BLEND: s rows                                             */
   float* out2;            /* GRU_BLEND: new h;   MUL_ACC: accumulator rows (+=)            */
   int32_t ld_aux;         /* leading dimension of aux0, aux1, out2                         */
+  const int32_t* a_rows;  /* NULL: A row of product row i is i; else a_rows[i] (gather)    */
+  const int32_t* c_rows;  /* NULL: product row i is output row i; else row c_rows[i] of C, */
+                          /* pre_out, add, aux0, aux1, out2 (scatter by message id)        */
+  int32_t zero_row;       /* GRU_BLEND: output row id whose out2 is forced to 0, -1 = none */
+  const int32_t* aux_sf;  /* MUL_ACC: if set, aux0 row r is read from slab                 */
+  int32_t aux_t;          /*   tau = min(aux_t, aux_sf[r] - 1) of aux0 (slab 0 == zero),   */
+  size_t aux_slab_stride; /*   slabs aux_slab_stride floats apart                          */
 } jtvae_epilogue_t;
 
 int jtvae_abi_version(void);
@@ -82,14 +90,16 @@ const char* jtvae_error_string(int code);
 int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
                   int32_t M, int32_t N, int32_t K, const jtvae_epilogue_t* epi, void* stream);
 
-/* dW[N,K] (+)= X[M,N]^T . Y[M,K]  - the weight gradient of C = Y.W^T given X = dC, reduced
- * over M in fixed order (split-M slabs + ordered slab sum: bitwise reproducible, no atomics).
- * Replaces autograd's addmm backward for every Linear on the path.
- * workspace: at least jtvae_gemm_tn_workspace_bytes(M,N,K) bytes of device memory. */
+/* dW[N,K] (+)= sum_m X[xr(m), 0:N]^T . Y[yr(m), 0:K]  - the weight gradient of C = Y.W^T given
+ * X = dC, reduced over M in fixed order (split-M slabs + ordered slab sum: bitwise reproducible, no
+ * atomics).  x_rows / y_rows (int32 [M], or NULL = identity) pick the row of X and of Y for every
+ * reduction index: the tree GRU contracts compactly stored gradient rows against saved state rows
+ * scattered over per-iteration slabs.  Replaces autograd's addmm backward for every Linear on the
+ * path.  workspace: at least jtvae_gemm_tn_workspace_bytes(M,N,K) bytes of device memory. */
 size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
-int jtvae_gemm_tn(const float* X, int32_t ldx, const float* Y, int32_t ldy, float* dW, int32_t lddw,
-                  int32_t M, int32_t N, int32_t K, int32_t accumulate, void* workspace,
-                  size_t workspace_bytes, void* stream);
+int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
+                  const int32_t* y_rows, float* dW, int32_t lddw, int32_t M, int32_t N, int32_t K,
+                  int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[c] (+)= sum_m X[m,c] for c < N (bias gradients), fixed summation order.
  * workspace: jtvae_colsum_workspace_bytes(M,N). */
@@ -138,36 +148,61 @@ int jtvae_segment_mean(float* out, const float* rows, const int32_t* seg, int32_
 int jtvae_segment_mean_bwd(float* drows, const float* dout, const float* act, const int32_t* seg,
                            const int32_t* seg_of, int32_t n_rows, int32_t H, int32_t ld, void* stream);
 
-/* ---- GraphGRU (fast_jtnn/jtnn_enc.py:107-128) ------------------------------------------- */
+/* ---- GraphGRU (fast_jtnn/jtnn_enc.py:107-128) -------------------------------------------
+ *
+ * Active rows.  The reference updates every message in each of the `depth` iterations.  The update
+ * is synchronous, h_{t+1}(m) = F(h_t of the messages m reads), so a message that reads nothing is
+ * constant from iteration 1 on and a message whose inputs are constant from iteration k on is
+ * constant from k+1 on ("stable_from", sf[m]; on a tree: the height of the sub-tree behind the
+ * message).  Re-computing a constant row gives the bit-identical value, so the entry points below
+ * take a LIST of row ids to update (`rows`, NULL = all n rows in order) and, for state kept per
+ * iteration in slabs `slab_stride` floats apart, read the value row j had at iteration t from slab
+ * min(t, sf[j]) (sf == NULL: single buffer, no slabs).  With rows == NULL and sf[j] >= depth this is
+ * the reference's dense schedule. */
 
-/* First iteration, where h == 0: z = sigmoid(Pz[wid]), p = tanh(Ph[wid]), h1 = z*p, row 0 -> 0.
- * Pz/Ph are per-word (or per-node) tables of W_z[:, :H].x + b_z and W_h[:, :H].x + b_h. */
+/* First iteration, where h == 0: z = sigmoid(Pz[wid]), p = tanh(Ph[wid]), h1 = z*p, row pad_row -> 0.
+ * Pz/Ph are per-word (or per-node) tables of W_z[:, :H].x + b_z and W_h[:, :H].x + b_h.
+ * z, p may be NULL (inference). */
 int jtvae_gru_iter0(const float* Pz, const float* Ph, const int32_t* wid, float* z, float* p,
-                    float* h1, int32_t n_mess, int32_t H, int32_t ld, void* stream);
+                    float* h1, int32_t n_mess, int32_t H, int32_t ld, int32_t pad_row, void* stream);
 
-/* One pass over the incoming messages of every message m (jtnn_enc.py:112-113, 117-122):
+/* One pass over the incoming messages of every active message m (jtnn_enc.py:112-113, 117-122):
  *   s[m] = sum_e h[j_e]
  *   g[m] = sum_e sigmoid(Pr[wid[m]] + Uh[j_e]) * h[j_e]        Uh = U_r h + b, once per message
  *   t[m] = sum_e r_e (1 - r_e) h[j_e]                         (t may be NULL: inference)
+ * h, Uh: slab 0 base pointers (see above).  s, g, t: output buffers indexed by message id.
  * The [NM,K,H] tensors h_nei, r, gated_h of the reference are never materialised. */
-int jtvae_gru_gate_gather(const float* h, const float* Uh, const float* Pr, const int32_t* wid,
-                          const int32_t* rowptr, const int32_t* col, float* s, float* g, float* t,
-                          int32_t n_mess, int32_t H, int32_t ld, void* stream);
+int jtvae_gru_gate_gather(const float* h, const float* Uh, size_t slab_stride, int32_t t_iter,
+                          const int32_t* sf, const float* Pr, const int32_t* wid, const int32_t* rowptr,
+                          const int32_t* col, const int32_t* rows, int32_t n_rows, float* s, float* g,
+                          float* t, int32_t H, int32_t ld, void* stream);
 
-/* Backward of the blend h' = ((1-z) s + z p) * mask (jtnn_enc.py:115,124-126):
- *   dzpre = dh (p - s) z (1-z);  dppre = dh z (1-p^2);  ds = dh (1-z);  row 0 -> 0. */
+/* Backward of the blend h' = ((1-z) s + z p) * mask (jtnn_enc.py:115,124-126) for the rows that
+ * receive gradient at iteration t_iter:
+ *   dzpre = dh (p - s) z (1-z);  dppre = dh z (1-p^2);  ds = dh (1-z);  dh[pad_row] taken as 0.
+ * z, p, s: slab 0 bases; row m is read from slab min(t_iter, sf[m]-1), s of slab 0 is zero.
+ * dzpre / dppre are written COMPACTLY (row i of the launch), ds by message id. */
 int jtvae_gru_bwd_pointwise(const float* dh, const float* z, const float* p, const float* s,
-                            float* dzpre, float* dppre, float* ds, int32_t n_mess, int32_t H,
-                            int32_t ld, void* stream);
+                            size_t slab_stride, int32_t t_iter, const int32_t* sf, const int32_t* rows,
+                            int32_t n_rows, float* dzpre, float* dppre, float* ds, int32_t H, int32_t ld,
+                            int32_t pad_row, void* stream);
 
 /* Backward of jtvae_gru_gate_gather with respect to h and Uh, over the TRANSPOSED graph
  * (trowptr/tcol: for message j, the messages m that read it), r recomputed:
- *   dUh[j]   = h[j] * sum_e dg[m_e] r_e (1 - r_e)
- *   dhdir[j] = sum_e ( ds[m_e] + dg[m_e] r_e )              r_e = sigmoid(Pr[wid[m_e]] + Uh[j]) */
-int jtvae_gru_bwd_gather(const float* h, const float* Uh, const float* Pr, const int32_t* wid,
-                         const float* dg, const float* ds, const int32_t* trowptr,
-                         const int32_t* tcol, float* dUh, float* dhdir, int32_t n_mess, int32_t H,
+ *   dUh[i]   = h[j] * sum_e dg[m_e] r_e (1 - r_e)             written compactly (row i of the launch)
+ *   dhdir[j] = sum_e ( ds[m_e] + dg[m_e] r_e )              r_e = sigmoid(Pr[wid[m_e]] + Uh[j])
+ * Readers m_e whose bit t_iter of active[m_e] is clear received no gradient and are skipped
+ * (active == NULL: none skipped). */
+int jtvae_gru_bwd_gather(const float* h, const float* Uh, size_t slab_stride, int32_t t_iter,
+                         const int32_t* sf, const uint64_t* active, const float* Pr, const int32_t* wid,
+                         const float* dg, const float* ds, const int32_t* trowptr, const int32_t* tcol,
+                         const int32_t* rows, int32_t n_rows, float* dUh, float* dhdir, int32_t H,
                          int32_t ld, void* stream);
+
+/* out[i] = slab sel[i] of base, row i: collects the final value of every message
+ * (sel[i] = min(depth, sf[i])). */
+int jtvae_select_slab_rows(float* out, const float* base, size_t slab_stride, const int32_t* sel,
+                           int32_t n_rows, int32_t H, int32_t ld, void* stream);
 
 /* ---- bilinear assembly score (fast_jtnn/jtnn_vae.py:112-114) ---------------------------- */
 

@@ -10,6 +10,10 @@
 //                                                         the (huge) row dimension, split
 //                                                         into slabs summed in fixed order
 //
+// Both take optional row lists: the tree GRU only updates the messages that can still
+// change in an iteration, so A rows are gathered and C rows scattered by message id, and the
+// weight gradients contract over a list of (gradient row, saved-state row) pairs.
+//
 // N = K = 450 on the hot calls, M = 4e4..9e5.  Tiles are cut for that: the NT block
 // is 128 rows x 96 columns (5 column blocks cover 480 >= 450: 6 % padding waste,
 // against 14 % for 128/256-wide tiles); one wave owns 32 rows x 96 columns = three
@@ -56,10 +60,9 @@ struct NtArgs {
 // zeroes what lies outside the matrix once the value is consumed.  A bounds check wrapped around
 // the load itself makes the compiler wait for each load separately, right where it is issued.
 template <bool VEC>
-__device__ __forceinline__ float4 load4_raw(const float* base, int ld, int row, int row_end, int k, int K) {
-  const int rc = min(row, row_end - 1);
+__device__ __forceinline__ float4 load4_raw(const float* rowbase, int k, int K) {
   const int kc = k < K ? k : 0;
-  const float* p = base + (size_t)rc * ld + kc;
+  const float* p = rowbase + kc;
   if (VEC) return *reinterpret_cast<const float4*>(p);  // k % 4 == 0 and ld % 4 == 0: inside the row
   const int last = K - 1 - kc;
   float4 v;
@@ -69,12 +72,11 @@ __device__ __forceinline__ float4 load4_raw(const float* base, int ld, int row, 
   v.w = p[min(3, last)];
   return v;
 }
-__device__ __forceinline__ float4 mask4(float4 v, int row, int row_end, int k, int K) {
-  const bool ok = row < row_end;
-  v.x = (ok && k + 0 < K) ? v.x : 0.f;
-  v.y = (ok && k + 1 < K) ? v.y : 0.f;
-  v.z = (ok && k + 2 < K) ? v.z : 0.f;
-  v.w = (ok && k + 3 < K) ? v.w : 0.f;
+__device__ __forceinline__ float4 mask4(float4 v, bool row_ok, int k, int K) {
+  v.x = (row_ok && k + 0 < K) ? v.x : 0.f;
+  v.y = (row_ok && k + 1 < K) ? v.y : 0.f;
+  v.z = (row_ok && k + 2 < K) ? v.z : 0.f;
+  v.w = (row_ok && k + 3 < K) ? v.w : 0.f;
   return v;
 }
 
@@ -87,7 +89,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-template <bool VEC>
+template <bool VEC, int MODE>
 __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   __shared__ __attribute__((aligned(16))) float As[NT_BM * NT_LDS];
   __shared__ __attribute__((aligned(16))) float Bs[NT_BN * NT_LDS];
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   const int tile = xcd_remap(blockIdx.x, a.n_blocks);
   const int m0 = (tile / a.n_tiles_n) * NT_BM;
   const int n0 = (tile % a.n_tiles_n) * NT_BN;
+  const jtvae_epilogue_t& e = a.e;
 
   f32x16 acc[NT_NT];
 #pragma unroll
@@ -109,22 +112,33 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   const int sc4 = tid & 7;
   float4 ra[NT_BM / 32], rb[NT_BN / 32];
 
-  const int n_rows_b = min(a.N, n0 + NT_BN);  // W rows this block may touch
+  // row base pointers of the staged rows do not change along K: resolve row lists once
+  const float* a_row[NT_BM / 32];
+  const float* b_row[NT_BN / 32];
+#pragma unroll
+  for (int i = 0; i < NT_BM / 32; ++i) {
+    int m = min(m0 + srow + 32 * i, a.M - 1);
+    if (e.a_rows) m = e.a_rows[m];
+    a_row[i] = a.A + (size_t)m * a.lda;
+  }
+#pragma unroll
+  for (int i = 0; i < NT_BN / 32; ++i) b_row[i] = a.W + (size_t)min(n0 + srow + 32 * i, a.N - 1) * a.ldw;
+
   auto load_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = load4_raw<VEC>(a.A, a.lda, m0 + srow + 32 * i, a.M, k0 + 4 * sc4, a.K);
+    for (int i = 0; i < NT_BM / 32; ++i) ra[i] = load4_raw<VEC>(a_row[i], k0 + 4 * sc4, a.K);
 #pragma unroll
-    for (int i = 0; i < NT_BN / 32; ++i) rb[i] = load4_raw<VEC>(a.W, a.ldw, n0 + srow + 32 * i, n_rows_b, k0 + 4 * sc4, a.K);
+    for (int i = 0; i < NT_BN / 32; ++i) rb[i] = load4_raw<VEC>(b_row[i], k0 + 4 * sc4, a.K);
   };
   auto store_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT_BM / 32; ++i)
       *reinterpret_cast<float4*>(&As[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
-          mask4(ra[i], m0 + srow + 32 * i, a.M, k0 + 4 * sc4, a.K);
+          mask4(ra[i], m0 + srow + 32 * i < a.M, k0 + 4 * sc4, a.K);
 #pragma unroll
     for (int i = 0; i < NT_BN / 32; ++i)
       *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
-          mask4(rb[i], n0 + srow + 32 * i, a.N, k0 + 4 * sc4, a.K);
+          mask4(rb[i], n0 + srow + 32 * i < a.N, k0 + 4 * sc4, a.K);
   };
 
   const int nk = (a.K + NT_BK - 1) / NT_BK;
@@ -167,49 +181,57 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   }
 
   // epilogue: accumulator register r of lane l is C[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31]
-  const jtvae_epilogue_t& e = a.e;
   const int col_in_tile = lane & 31;
 #pragma unroll
-  for (int t = 0; t < NT_NT; ++t) {
-    const int n = n0 + 32 * t + col_in_tile;
-    const bool n_ok = n < a.N;
-    const float bias = (e.bias && n_ok) ? e.bias[n] : 0.f;
+  for (int r = 0; r < 16; ++r) {
+    const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (i >= a.M) continue;
+    const int m = e.c_rows ? e.c_rows[i] : i;  // id of the output row
+    float* c_row = a.C + (size_t)m * a.ldc;
+    const float* add_row = nullptr;
+    if (e.add) add_row = e.add + (size_t)(e.add_idx ? e.add_idx[m] : m) * e.ld_add;
+    const size_t aux_off = (size_t)m * e.ld_aux;
+    const float* mul_row = nullptr;  // MUL_ACC multiplier row, possibly out of a per-iteration slab
+    if (MODE == JTVAE_EPI_MUL_ACC) {
+      if (e.aux_sf) {
+        const int tau = min(e.aux_t, e.aux_sf[m] - 1);
+        if (tau > 0) mul_row = e.aux0 + (size_t)tau * e.aux_slab_stride + aux_off;  // slab 0 is all zero
+      } else {
+        mul_row = e.aux0 + aux_off;
+      }
+    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m >= a.M) continue;
-      if (!n_ok) {
+    for (int t = 0; t < NT_NT; ++t) {
+      const int n = n0 + 32 * t + col_in_tile;
+      if (n >= a.N) {
         // padding columns of the outputs are defined as zero
-        if (n < a.ldc) a.C[(size_t)m * a.ldc + n] = 0.f;
-        if (e.pre_out && n < e.ld_pre) e.pre_out[(size_t)m * e.ld_pre + n] = 0.f;
-        if (e.mode == JTVAE_EPI_GRU_BLEND && n < e.ld_aux) e.out2[(size_t)m * e.ld_aux + n] = 0.f;
+        if (n < a.ldc) c_row[n] = 0.f;
+        if (MODE == JTVAE_EPI_PLAIN && e.pre_out && n < e.ld_pre) e.pre_out[(size_t)m * e.ld_pre + n] = 0.f;
+        if (MODE == JTVAE_EPI_GRU_BLEND && n < e.ld_aux) e.out2[aux_off + n] = 0.f;
         continue;
       }
-      float v = acc[t][r] + bias;
-      if (e.add) {
-        const int ar = e.add_idx ? e.add_idx[m] : m;
-        v += e.add[(size_t)ar * e.ld_add + n];
-      }
-      if (e.mode == JTVAE_EPI_PLAIN) {
+      float v = acc[t][r];
+      if (e.bias) v += e.bias[n];
+      if (add_row) v += add_row[n];
+      if (MODE == JTVAE_EPI_PLAIN) {
         if (e.pre_out) e.pre_out[(size_t)m * e.ld_pre + n] = v;
-        a.C[(size_t)m * a.ldc + n] = act_apply(v, e.act);
-      } else if (e.mode == JTVAE_EPI_GRU_BLEND) {
+        c_row[n] = act_apply(v, e.act);
+      } else if (MODE == JTVAE_EPI_GRU_BLEND) {
         const float p = tanhf(v);
-        const float z = e.aux0[(size_t)m * e.ld_aux + n];
-        const float s = e.aux1[(size_t)m * e.ld_aux + n];
-        a.C[(size_t)m * a.ldc + n] = p;
-        e.out2[(size_t)m * e.ld_aux + n] = (m == 0) ? 0.f : fmaf(z, p - s, s);  // (1-z)s + zp
+        const float z = e.aux0[aux_off + n];
+        const float s = e.aux1[aux_off + n];
+        c_row[n] = p;
+        e.out2[aux_off + n] = (m == e.zero_row) ? 0.f : fmaf(z, p - s, s);  // (1-z)s + zp
       } else {  // JTVAE_EPI_MUL_ACC
-        a.C[(size_t)m * a.ldc + n] = v;
-        const size_t o = (size_t)m * e.ld_aux + n;
-        e.out2[o] = fmaf(v, e.aux0[o], e.out2[o]);
+        c_row[n] = v;
+        if (mul_row) e.out2[aux_off + n] = fmaf(v, mul_row[n], e.out2[aux_off + n]);
       }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------
-// gemm_tn: partial[s][n][k] = sum_{m in slab s} X[m][n] * Y[m][k]
+// gemm_tn: partial[s][n][k] = sum_{m in slab s} X[xr(m)][n] * Y[yr(m)][k]
 // Block tile 128 (n) x 96 (k); wave w owns n rows [32w, 32w+32) and three 32x32 accumulators.
 // Operand tiles sit in LDS row-major as loaded (m-major): for one MFMA step lane l needs
 // X[m = 2*step + (l>>5)][n = l&31], i.e. 32 consecutive floats per half-wave: conflict-free
@@ -221,7 +243,9 @@ constexpr int TN_BM = 32;
 struct TnArgs {
   const float* X;
   const float* Y;
-  float* P;  // [splits][N][ldp]
+  const int* x_rows;  // nullable: row of X for reduction index m
+  const int* y_rows;  // nullable: row of Y for reduction index m
+  float* P;           // [splits][N][ldp]
   int ldx, ldy, ldp;
   int M, N, K;
   int tiles_n, tiles_k, rows_per_split;
@@ -247,42 +271,56 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   float4 rx[4], ry[3];
-  auto load_tiles = [&](int mb) {
+  int ix[4], iy[3];  // source rows of the NEXT tile to load (row lists resolved one tile ahead)
+  auto load_rows = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int idx = tid + 256 * i;  // 32 rows x 32 float4
-      rx[i] = load4_raw<VEC>(a.X, a.ldx, mb + (idx >> 5), m_end, n0 + 4 * (idx & 31), a.N);
+      int m = min(mb + ((tid + 256 * i) >> 5), m_end - 1);
+      ix[i] = a.x_rows ? a.x_rows[m] : m;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      int idx = tid + 256 * i;  // 32 rows x 24 float4
-      ry[i] = load4_raw<VEC>(a.Y, a.ldy, mb + idx / 24, m_end, k0 + 4 * (idx % 24), a.K);
+      int m = min(mb + (tid + 256 * i) / 24, m_end - 1);
+      iy[i] = a.y_rows ? a.y_rows[m] : m;
     }
+  };
+  auto load_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      rx[i] = load4_raw<VEC>(a.X + (size_t)ix[i] * a.ldx, n0 + 4 * ((tid + 256 * i) & 31), a.N);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      ry[i] = load4_raw<VEC>(a.Y + (size_t)iy[i] * a.ldy, k0 + 4 * ((tid + 256 * i) % 24), a.K);
   };
   auto store_tiles = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int idx = tid + 256 * i;
       *reinterpret_cast<float4*>(&Xs[(idx >> 5) * TN_BN + 4 * (idx & 31)]) =
-          mask4(rx[i], mb + (idx >> 5), m_end, n0 + 4 * (idx & 31), a.N);
+          mask4(rx[i], mb + (idx >> 5) < m_end, n0 + 4 * (idx & 31), a.N);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       int idx = tid + 256 * i;
       *reinterpret_cast<float4*>(&Ys[(idx / 24) * TN_BKK + 4 * (idx % 24)]) =
-          mask4(ry[i], mb + idx / 24, m_end, k0 + 4 * (idx % 24), a.K);
+          mask4(ry[i], mb + idx / 24 < m_end, k0 + 4 * (idx % 24), a.K);
     }
   };
 
   if (m_beg < m_end) {
-    load_tiles(m_beg);
+    load_rows(m_beg);
+    load_tiles();
     store_tiles(m_beg);
+    if (m_beg + TN_BM < m_end) load_rows(m_beg + TN_BM);
     __syncthreads();
     const float* xf = &Xs[(lane >> 5) * TN_BN + wave * 32 + (lane & 31)];
     const float* yf = &Ys[(lane >> 5) * TN_BKK + (lane & 31)];
     for (int mb = m_beg; mb < m_end; mb += TN_BM) {
       const bool more = mb + TN_BM < m_end;
-      if (more) load_tiles(mb + TN_BM);
+      if (more) {
+        load_tiles();                                            // tile mb + TN_BM, rows known already
+        if (mb + 2 * TN_BM < m_end) load_rows(mb + 2 * TN_BM);   // row ids of the tile after it
+      }
 #pragma unroll
       for (int st = 0; st < TN_BM / 2; ++st) {
         float xv = xf[2 * st * TN_BN];
@@ -383,6 +421,20 @@ inline TnPlan tn_plan(int M, int N, int K) {
   return p;
 }
 
+template <bool VEC>
+void launch_nt(const NtArgs& a, hipStream_t s) {
+  switch (a.e.mode) {
+    case JTVAE_EPI_GRU_BLEND:
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_GRU_BLEND>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      break;
+    case JTVAE_EPI_MUL_ACC:
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_MUL_ACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_PLAIN>), dim3(a.n_blocks), dim3(256), 0, s, a);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -400,9 +452,7 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
     a.e = *epi;
   } else {
     a.e = jtvae_epilogue_t();
-    a.e.bias = nullptr; a.e.add = nullptr; a.e.add_idx = nullptr; a.e.pre_out = nullptr;
-    a.e.aux0 = nullptr; a.e.aux1 = nullptr; a.e.out2 = nullptr;
-    a.e.ld_add = a.e.ld_pre = a.e.ld_aux = 0; a.e.act = 0; a.e.mode = 0;
+    a.e.zero_row = -1;
   }
   const jtvae_epilogue_t& e = a.e;
   if (e.mode < 0 || e.mode > JTVAE_EPI_MUL_ACC || e.act < 0 || e.act > JTVAE_ACT_TANH) return JTVAE_E_RANGE;
@@ -410,15 +460,16 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
   if (e.pre_out && e.ld_pre < N) return JTVAE_E_SHAPE;
   if (e.mode == JTVAE_EPI_GRU_BLEND && (!e.aux0 || !e.aux1 || !e.out2 || e.ld_aux < N)) return JTVAE_E_NULL;
   if (e.mode == JTVAE_EPI_MUL_ACC && (!e.aux0 || !e.out2 || e.ld_aux < N)) return JTVAE_E_NULL;
+  if (e.aux_sf && e.aux_t < 0) return JTVAE_E_SHAPE;
   int tiles_m = (M + NT_BM - 1) / NT_BM;
   a.n_tiles_n = (N + NT_BN - 1) / NT_BN;
   a.n_blocks = tiles_m * a.n_tiles_n;
   const bool vec = aligned16(A, lda) && aligned16(W, ldw);
   hipStream_t s = (hipStream_t)stream;
   if (vec)
-    hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(a.n_blocks), dim3(256), 0, s, a);
+    launch_nt<true>(a, s);
   else
-    hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(a.n_blocks), dim3(256), 0, s, a);
+    launch_nt<false>(a, s);
   return launch_status();
 }
 
@@ -428,16 +479,16 @@ size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   return (size_t)p.splits * N * p.ldp * sizeof(float);
 }
 
-int jtvae_gemm_tn(const float* X, int32_t ldx, const float* Y, int32_t ldy, float* dW, int32_t lddw, int32_t M,
-                  int32_t N, int32_t K, int32_t accumulate, void* workspace, size_t workspace_bytes,
-                  void* stream) {
+int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
+                  const int32_t* y_rows, float* dW, int32_t lddw, int32_t M, int32_t N, int32_t K,
+                  int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || ldx < N || ldy < K || lddw < K) return JTVAE_E_SHAPE;
   if (!X || !Y || !dW || !workspace) return JTVAE_E_NULL;
   TnPlan p = tn_plan(M, N, K);
   if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float)) return JTVAE_E_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(workspace) & 15) return JTVAE_E_ALIGN;
   TnArgs a;
-  a.X = X; a.Y = Y; a.P = (float*)workspace;
+  a.X = X; a.Y = Y; a.x_rows = x_rows; a.y_rows = y_rows; a.P = (float*)workspace;
   a.ldx = ldx; a.ldy = ldy; a.ldp = p.ldp;
   a.M = M; a.N = N; a.K = K;
   a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.rows_per_split = p.rows_per_split;

@@ -42,6 +42,12 @@ class Epilogue(C.Structure):
         ("aux1", C.c_void_p),
         ("out2", C.c_void_p),
         ("ld_aux", C.c_int32),
+        ("a_rows", C.c_void_p),
+        ("c_rows", C.c_void_p),
+        ("zero_row", C.c_int32),
+        ("aux_sf", C.c_void_p),
+        ("aux_t", C.c_int32),
+        ("aux_slab_stride", C.c_size_t),
     ]
 
 
@@ -53,7 +59,7 @@ SIGNATURES = {
     "jtvae_error_string": (C.c_char_p, [C.c_int]),
     "jtvae_gemm_nt": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
     "jtvae_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "jtvae_gemm_tn": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "jtvae_gemm_tn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "jtvae_colsum_workspace_bytes": (_sz, [_i32, _i32]),
     "jtvae_colsum": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "jtvae_transpose": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
@@ -62,10 +68,14 @@ SIGNATURES = {
     "jtvae_slab_sum": (C.c_int, [_vp, _vp, _i32, _sz, _i32, _i32, _i32, _vp]),
     "jtvae_segment_mean": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_segment_mean_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "jtvae_gru_iter0": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "jtvae_gru_gate_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "jtvae_gru_bwd_pointwise": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "jtvae_gru_bwd_gather": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_gru_iter0": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "jtvae_gru_gate_gather": (C.c_int, [_vp, _vp, _sz, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                        _i32, _i32, _vp]),
+    "jtvae_gru_bwd_pointwise": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
+                                          _i32, _vp]),
+    "jtvae_gru_bwd_gather": (C.c_int, [_vp, _vp, _sz, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
+                                       _vp, _i32, _i32, _vp]),
+    "jtvae_select_slab_rows": (C.c_int, [_vp, _vp, _sz, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_row_dot": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
 }
 
@@ -176,18 +186,20 @@ def _run(name, fn, args, nbytes=0, flops=0):
 
 def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0, add_idx=None,
             act=ACT_NONE, pre_out=None, ld_pre=0, mode=EPI_PLAIN, aux0=None, aux1=None, out2=None,
-            ld_aux=0):
-    e = Epilogue(bias, add, ld_add, add_idx, act, pre_out, ld_pre, mode, aux0, aux1, out2, ld_aux)
+            ld_aux=0, a_rows=None, c_rows=None, zero_row=-1, aux_sf=None, aux_t=0, aux_slab_stride=0):
+    e = Epilogue(bias, add, ld_add, add_idx, act, pre_out, ld_pre, mode, aux0, aux1, out2, ld_aux,
+                 a_rows, c_rows, zero_row, aux_sf, aux_t, aux_slab_stride)
     extra = (1 if add else 0) + (1 if pre_out else 0) + {EPI_PLAIN: 0, EPI_GRU_BLEND: 3, EPI_MUL_ACC: 3}[mode]
     _run("gemm_nt", lib.jtvae_gemm_nt, (A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()),
          nbytes=4 * (M * K + N * K + M * N * (1 + extra)), flops=2 * M * N * K)
 
 
-def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device):
+def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device, x_rows=None, y_rows=None):
     nbytes = lib.jtvae_gemm_tn_workspace_bytes(M, N, K)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-    _run("gemm_tn", lib.jtvae_gemm_tn, (X, ldx, Y, ldy, dW, lddw, M, N, K, int(accumulate), ws.data_ptr(), nbytes,
-                                        stream_ptr()), nbytes=4 * (M * N + M * K + N * K), flops=2 * M * N * K)
+    _run("gemm_tn", lib.jtvae_gemm_tn, (X, ldx, x_rows, Y, ldy, y_rows, dW, lddw, M, N, K, int(accumulate),
+                                        ws.data_ptr(), nbytes, stream_ptr()),
+         nbytes=4 * (M * N + M * K + N * K), flops=2 * M * N * K)
 
 
 def colsum(X, ldx, out, M, N, accumulate, device):
@@ -233,28 +245,37 @@ def segment_mean_bwd(drows, dout, act, seg, seg_of, n_rows, H, ld, n_seg=0):
          nbytes=4 * H * (2 * n_rows + n_seg) + 4 * n_rows)
 
 
-def gru_iter0(Pz, Ph, wid, z, p, h1, n_mess, H, ld):
-    _run("gru_iter0", lib.jtvae_gru_iter0, (Pz, Ph, wid, z, p, h1, n_mess, H, ld, stream_ptr()),
-         nbytes=4 * H * n_mess * 5 + 4 * n_mess)
+def gru_iter0(Pz, Ph, wid, z, p, h1, n_mess, H, ld, pad_row=0):
+    _run("gru_iter0", lib.jtvae_gru_iter0, (Pz, Ph, wid, z, p, h1, n_mess, H, ld, pad_row, stream_ptr()),
+         nbytes=4 * H * n_mess * (5 if z else 3) + 4 * n_mess)
 
 
-def gru_gate_gather(h, Uh, Pr, wid, rowptr, col, s, g, t, n_mess, H, ld, nnz=None):
+def gru_gate_gather(h, Uh, slab_stride, t_iter, sf, Pr, wid, rowptr, col, rows, n_rows, s, g, t, H, ld, nnz=None):
     # rows: h and Uh per edge, the W_r x table row per message, s / g (/ t) written
-    nbytes = 0 if nnz is None else 4 * H * (2 * nnz + n_mess * (1 + (3 if t else 2))) + 4 * (2 * n_mess + 1 + nnz)
+    nbytes = 0 if nnz is None else 4 * H * (2 * nnz + n_rows * (1 + (3 if t else 2))) + 4 * (3 * n_rows + nnz)
     _run("gru_gate_gather", lib.jtvae_gru_gate_gather,
-         (h, Uh, Pr, wid, rowptr, col, s, g, t, n_mess, H, ld, stream_ptr()), nbytes=nbytes)
+         (h, Uh, slab_stride, t_iter, sf, Pr, wid, rowptr, col, rows, n_rows, s, g, t, H, ld, stream_ptr()),
+         nbytes=nbytes)
 
 
-def gru_bwd_pointwise(dh, z, p, s, dzpre, dppre, ds, n_mess, H, ld):
+def gru_bwd_pointwise(dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre, dppre, ds, H, ld, pad_row=0):
     _run("gru_bwd_pointwise", lib.jtvae_gru_bwd_pointwise,
-         (dh, z, p, s, dzpre, dppre, ds, n_mess, H, ld, stream_ptr()), nbytes=4 * H * n_mess * 7)
+         (dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre, dppre, ds, H, ld, pad_row, stream_ptr()),
+         nbytes=4 * H * n_rows * 7 + 8 * n_rows)
 
 
-def gru_bwd_gather(h, Uh, Pr, wid, dg, ds, trowptr, tcol, dUh, dhdir, n_mess, H, ld, nnz=None):
+def gru_bwd_gather(h, Uh, slab_stride, t_iter, sf, active, Pr, wid, dg, ds, trowptr, tcol, rows, n_rows, dUh,
+                   dhdir, H, ld, nnz=None):
     # rows: h, Uh read and dUh, dhdir written per message; table row, dg, ds read per edge
-    nbytes = 0 if nnz is None else 4 * H * (4 * n_mess + 3 * nnz) + 4 * (n_mess + 1 + 2 * nnz)
+    nbytes = 0 if nnz is None else 4 * H * (4 * n_rows + 3 * nnz) + 4 * (2 * n_rows + 2 * nnz)
     _run("gru_bwd_gather", lib.jtvae_gru_bwd_gather,
-         (h, Uh, Pr, wid, dg, ds, trowptr, tcol, dUh, dhdir, n_mess, H, ld, stream_ptr()), nbytes=nbytes)
+         (h, Uh, slab_stride, t_iter, sf, active, Pr, wid, dg, ds, trowptr, tcol, rows, n_rows, dUh, dhdir, H, ld,
+          stream_ptr()), nbytes=nbytes)
+
+
+def select_slab_rows(out, base, slab_stride, sel, n_rows, H, ld):
+    _run("select_slab_rows", lib.jtvae_select_slab_rows, (out, base, slab_stride, sel, n_rows, H, ld, stream_ptr()),
+         nbytes=8 * H * n_rows + 4 * n_rows)
 
 
 def row_dot(score, q, owner, cand, n_cand, H, ld):

@@ -206,6 +206,8 @@ class TreePrep:
     key_r_pieces: DeviceCSR
     key_r: DeviceCSR
     vocab_size: int
+    host: dict = None  # numpy copies needed to build schedules lazily
+    schedules: dict = None  # (T, dense) -> TreeSchedule
 
 
 KEY_CHUNK = 32
@@ -264,7 +266,203 @@ def prepare_tree(holder, device, vocab_size: int) -> TreePrep:
         ident=upload_csr(ar, ar[:-1], device),
         key_m_pieces=km_p, key_m=km, key_r_pieces=kr_p, key_r=kr,
         vocab_size=vocab_size,
+        host=dict(m_rp=m_rp, m_col=m_col, mt_rp=mt_rp, mt_col=mt_col, wid_m=wid_m, r_col=r_col, device=device),
+        schedules={},
     )
+
+
+def tree_schedule(prep: TreePrep, T: int, dense: bool = False) -> TreeSchedule:
+    key = (T, bool(dense))
+    if key not in prep.schedules:
+        h = prep.host
+        prep.schedules[key] = build_tree_schedule(h["m_rp"], h["m_col"], h["mt_rp"], h["mt_col"], prep.n_mess, T,
+                                                  h["device"], dense)
+    return prep.schedules[key]
+
+
+def backward_schedule(prep: TreePrep, sched: TreeSchedule, all_messages: bool) -> BackwardSchedule:
+    """all_messages: the caller's gradient reaches every message (JTMPN reads them); otherwise only the
+    messages flowing into a root node carry gradient (tree_vecs is the only consumer)."""
+    key = "all" if all_messages else "roots"
+    if key not in sched.bwd:
+        h = prep.host
+        seeds = None if all_messages else h["r_col"]
+        sched.bwd[key] = build_backward_schedule(sched, seeds, h["wid_m"], prep.n_words, h["device"])
+    return sched.bwd[key]
+
+
+# ---- active-row schedule of the tree GRU ---------------------------------------------------
+
+
+@dataclass
+class RowList:
+    rows: Optional[torch.Tensor]  # int32 [n] message ids, None = all messages in order
+    n: int
+    nnz: int = 0  # graph entries touched by these rows (for traffic accounting)
+
+    def ptr(self):
+        return None if self.rows is None else self.rows.data_ptr()
+
+
+@dataclass
+class BackwardSchedule:
+    """Which messages receive gradient at which iteration, and where their rows are stored.
+
+    Walking back from iteration T-1: E[t] are the messages whose h_{t+1} has a non-zero gradient,
+    J[t] = the messages they read (= E[t-1]).  Pre-activation gradients of E[t] are stored compactly
+    at rows [offE[t], offE[t]+n), the U_r-product gradients of J[t] at [offJ[t], ...).
+    """
+
+    E: list  # RowList per iteration t
+    J: list  # RowList per iteration t (J[0] unused)
+    offE: list
+    offJ: list
+    nE: int
+    nJ: int
+    active: Optional[torch.Tensor]  # int64 bitmask per message: bit t set <=> message in E[t]
+    # weight-gradient contraction lists (compact gradient row, saved-state row in the slab array)
+    zx: torch.Tensor
+    zy: torch.Tensor
+    n_z: int
+    ux: torch.Tensor
+    uy: torch.Tensor
+    n_u: int
+    key_pieces: DeviceCSR  # compact E rows grouped by word-table row
+    key: DeviceCSR
+
+
+@dataclass
+class TreeSchedule:
+    T: int
+    dense: bool
+    sf: torch.Tensor  # int32 [NM] iteration from which a message no longer changes (capped at T)
+    sel_final: torch.Tensor  # int32 [NM] slab that holds the final value: min(T, sf)
+    F: list  # RowList per iteration: messages to update (sf > t)
+    U: list  # RowList per iteration t >= 1: messages whose U_r product is needed (changed at t-1, have readers)
+    bwd: dict  # "all" / "roots" -> BackwardSchedule, built on first use
+    _host: dict = None
+
+
+def _levels(rowptr, col, n, cap, start):
+    """level[m] = start if row m has no entries else 1 + max(level[col entries]), capped."""
+    deg = np.diff(rowptr)
+    row_of = np.repeat(np.arange(n, dtype=np.int64), deg)
+    lev = np.full(n, start, dtype=np.int64)
+    for _ in range(cap + 1):
+        mx = np.full(n, start - 1, dtype=np.int64)
+        if col.size:
+            np.maximum.at(mx, row_of, lev[col])
+        new = np.minimum(np.where(deg > 0, mx + 1, start), cap)
+        if np.array_equal(new, lev):
+            break
+        lev = new
+    return lev
+
+
+def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False) -> TreeSchedule:
+    deg = np.diff(m_rp)
+    tdeg = np.diff(mt_rp)
+    if dense or T < 1:
+        sf = np.full(nm, max(T, 1), dtype=np.int64)
+    else:
+        sf = _levels(m_rp, m_col, nm, max(T, 1), 1)
+    F, U = [], []
+    total_nnz = int(m_col.shape[0])
+    for t in range(T):
+        if dense or t == 0:
+            F.append(RowList(None, nm, total_nnz))
+        else:
+            r = np.flatnonzero(sf > t)
+            F.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size), int(deg[r].sum())))
+        if t == 0:
+            U.append(RowList(None, 0))
+        elif dense:
+            U.append(RowList(None, nm))
+        else:
+            r = np.flatnonzero((sf >= t) & (tdeg > 0))  # changed in iteration t-1 and somebody reads it
+            U.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size)))
+    host = dict(m_rp=m_rp, m_col=m_col, mt_rp=mt_rp, mt_col=mt_col, sf=sf, nm=nm, deg=deg, tdeg=tdeg)
+    return TreeSchedule(T=T, dense=dense, sf=_dev_i32(sf, device), sel_final=_dev_i32(np.minimum(sf, T), device),
+                        F=F, U=U, bwd={}, _host=host)
+
+
+def build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], wid_m: np.ndarray, n_words: int,
+                            device) -> BackwardSchedule:
+    """seeds: message ids with a non-zero external gradient on the final h (None = all)."""
+    h = sched._host
+    nm, T, sf = h["nm"], sched.T, h["sf"]
+    m_rp, m_col, deg = h["m_rp"], h["m_col"], h["deg"]
+    E = [None] * T
+    use_mask = (not sched.dense) and T <= 63
+    if sched.dense or not use_mask:
+        sets = [np.arange(nm, dtype=np.int64)] * T
+    else:
+        cur = np.arange(nm, dtype=np.int64) if seeds is None else np.unique(seeds.astype(np.int64))
+        sets = [None] * T
+        for t in range(T - 1, -1, -1):
+            sets[t] = cur
+            if cur.size == 0:
+                for u in range(t - 1, -1, -1):
+                    sets[u] = cur
+                break
+            # messages read by the current set
+            starts, cnt = m_rp[cur], deg[cur]
+            if int(cnt.sum()) == 0:
+                cur = cur[:0]
+            else:
+                idx = np.repeat(starts - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
+                cur = np.unique(m_col[idx])
+    offE, offJ = [0] * T, [0] * T
+    nE = nJ = 0
+    active = np.zeros(nm, dtype=np.int64)
+    El, Jl = [], []
+    tdeg = h["tdeg"]
+    for t in range(T):
+        r = sets[t]
+        offE[t] = nE
+        nE += int(r.size)
+        full = r.size == nm
+        El.append(RowList(None if full else (_dev_i32(r, device) if r.size else None), int(r.size)))
+        if use_mask and r.size:
+            active[r] |= np.int64(1) << np.int64(t)
+    for t in range(T):
+        if t == 0:
+            Jl.append(RowList(None, 0))
+            continue
+        r = sets[t - 1]
+        offJ[t] = nJ
+        nJ += int(r.size)
+        full = r.size == nm
+        Jl.append(RowList(None if full else (_dev_i32(r, device) if r.size else None), int(r.size),
+                          int(tdeg[r].sum())))
+    # weight-gradient contraction lists
+    zx, zy, ux, uy, keys = [], [], [], [], []
+    for t in range(T):
+        r = sets[t]
+        if r.size == 0:
+            continue
+        keys.append(wid_m[r])
+        if t >= 1:
+            tau = np.minimum(t, sf[r] - 1)
+            ok = tau >= 1  # iteration 0 has s == g == 0: no contribution
+            zx.append(offE[t] + np.flatnonzero(ok))
+            zy.append(tau[ok] * nm + r[ok])
+            j = sets[t - 1]
+            if j.size:
+                ux.append(offJ[t] + np.arange(j.size))
+                uy.append(np.minimum(t, sf[j]) * nm + j)
+    cat = lambda l: np.concatenate(l) if l else np.zeros(0, dtype=np.int64)  # noqa: E731
+    zx, zy, ux, uy, keys = cat(zx), cat(zy), cat(ux), cat(uy), cat(keys)
+    if (T + 1) * nm >= 2 ** 31:
+        raise OverflowError("slab row index exceeds int32")
+    kp, kc = _key_lists(keys.astype(np.int64), n_words, device)
+    one = np.zeros(1, dtype=np.int64)
+    return BackwardSchedule(
+        E=El, J=Jl, offE=offE, offJ=offJ, nE=nE, nJ=nJ,
+        active=torch.from_numpy(active).to(device) if use_mask else None,
+        zx=_dev_i32(zx if zx.size else one, device), zy=_dev_i32(zy if zy.size else one, device), n_z=int(zx.size),
+        ux=_dev_i32(ux if ux.size else one, device), uy=_dev_i32(uy if uy.size else one, device), n_u=int(ux.size),
+        key_pieces=kp, key=kc)
 
 
 # ---- caching on the holder object --------------------------------------------------------

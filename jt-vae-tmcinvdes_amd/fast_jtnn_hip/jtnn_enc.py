@@ -32,91 +32,105 @@ from . import graphprep
 from .mpn import _pack_weight, _pack_weight_t, as_row_buffer, dense_view
 
 
-class _TreeGRU:
-    """Shared forward/backward body of GraphGRU, on padded row buffers.
+SCHEDULE = "level"  # "level": update only messages that can still change; "dense": the reference's schedule
 
-    Tables Pz, Pr, Ph are [n_words, ld]; wid maps a message to its table row.
+
+class _TreeGRU:
+    """Forward/backward body of GraphGRU on padded row buffers, driven by an active-row schedule.
+
+    Tables Pz, Pr, Ph are [n_words, ld]; wid maps a message to its table row.  Per-iteration state
+    (training) lives in slabs [T(+1), NM, ld] of which only the rows of the schedule are written.
     """
 
     @staticmethod
-    def forward(h0_is_zero, depth, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur, bu, Whh, train):
-        T = depth
-        st = {}
+    def forward(sched, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur, bu, Whh, train, pad_row=0):
+        T = sched.T
+        wid_p = wid.data_ptr()
+        if T == 0:
+            return K.rows(NM, ld, dev, zero=True), {}
         if train:
             hs = torch.empty((T + 1, NM, ld), dtype=torch.float32, device=dev)
-            hs[0].zero_()
-            zs = torch.empty((T, NM, ld), dtype=torch.float32, device=dev)
-            ps = torch.empty_like(zs)
-            ss = torch.empty_like(zs)
-            gs = torch.empty_like(zs)
-            ts = torch.empty_like(zs)
-            us = torch.empty_like(zs)
-            ss[0].zero_()
+            zs, ps, ss, gs, ts, us = (torch.empty((T, NM, ld), dtype=torch.float32, device=dev) for _ in range(6))
+            stride = NM * ld
+            sf_p = sched.sf.data_ptr()
             st = dict(hs=hs, zs=zs, ps=ps, ss=ss, gs=gs, ts=ts, us=us)
+            K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, zs[0].data_ptr(), ps[0].data_ptr(), hs[1].data_ptr(),
+                        NM, H, ld, pad_row)
         else:
-            hs = torch.empty((2, NM, ld), dtype=torch.float32, device=dev)
-            zs = torch.empty((1, NM, ld), dtype=torch.float32, device=dev)
-            ps, ss, gs, us = (torch.empty_like(zs) for _ in range(4))
-            ts = None
-        assert h0_is_zero
-        if T == 0:
-            hs[0].zero_()
-            return hs[0], st
-        wid_p = wid.data_ptr()
-        # iteration 0: every neighbour sum is zero
-        h_next = hs[1]
-        K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, zs[0].data_ptr(), ps[0].data_ptr(), h_next.data_ptr(),
-                    NM, H, ld)
+            # inference: one buffer each, updated in place (frozen rows simply keep their value)
+            hs = torch.empty((1, NM, ld), dtype=torch.float32, device=dev)
+            zs, ps, ss, gs, us = (torch.empty((1, NM, ld), dtype=torch.float32, device=dev) for _ in range(5))
+            stride, sf_p, st = 0, None, {}
+            K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, None, None, hs[0].data_ptr(), NM, H, ld, pad_row)
         for t in range(1, T):
+            F, U = sched.F[t], sched.U[t]
+            if F.n == 0:
+                break  # every message has reached its fixed point
             i = t if train else 0
-            h = hs[t] if train else hs[t & 1]
-            h_next = hs[t + 1] if train else hs[(t + 1) & 1]
-            # Uh = U_r h + b
-            K.gemm_nt(h.data_ptr(), ld, Ur.data_ptr(), ld, us[i].data_ptr(), ld, NM, H, H, bias=bu.data_ptr())
-            K.gru_gate_gather(h.data_ptr(), us[i].data_ptr(), Pr.data_ptr(), wid_p, mcsr.rowptr.data_ptr(),
-                              mcsr.col.data_ptr(), ss[i].data_ptr(), gs[i].data_ptr(),
-                              ts[i].data_ptr() if train else None, NM, H, ld, nnz=mcsr.nnz)
+            h_in = hs[t] if train else hs[0]
+            h_out = hs[t + 1] if train else hs[0]
+            # Uh = U_r h + b for the messages that changed in the last iteration and are read by someone
+            K.gemm_nt(h_in.data_ptr(), ld, Ur.data_ptr(), ld, us[i].data_ptr(), ld, U.n, H, H, bias=bu.data_ptr(),
+                      a_rows=U.ptr(), c_rows=U.ptr())
+            K.gru_gate_gather(hs.data_ptr(), us.data_ptr(), stride, t, sf_p, Pr.data_ptr(), wid_p,
+                              mcsr.rowptr.data_ptr(), mcsr.col.data_ptr(), F.ptr(), F.n, ss[i].data_ptr(),
+                              gs[i].data_ptr(), ts[i].data_ptr() if train else None, H, ld, nnz=F.nnz)
             # z = sigmoid(W_z[:, H:] s + Pz[wid])
-            K.gemm_nt(ss[i].data_ptr(), ld, Wzh.data_ptr(), ld, zs[i].data_ptr(), ld, NM, H, H,
-                      add=Pz.data_ptr(), ld_add=ld, add_idx=wid_p, act=K.ACT_SIGMOID)
+            K.gemm_nt(ss[i].data_ptr(), ld, Wzh.data_ptr(), ld, zs[i].data_ptr(), ld, F.n, H, H,
+                      add=Pz.data_ptr(), ld_add=ld, add_idx=wid_p, act=K.ACT_SIGMOID, a_rows=F.ptr(), c_rows=F.ptr())
             # p = tanh(W_h[:, H:] g + Ph[wid]);  h' = (1-z) s + z p, padding row kept zero
-            K.gemm_nt(gs[i].data_ptr(), ld, Whh.data_ptr(), ld, ps[i].data_ptr(), ld, NM, H, H,
+            K.gemm_nt(gs[i].data_ptr(), ld, Whh.data_ptr(), ld, ps[i].data_ptr(), ld, F.n, H, H,
                       add=Ph.data_ptr(), ld_add=ld, add_idx=wid_p, mode=K.EPI_GRU_BLEND,
-                      aux0=zs[i].data_ptr(), aux1=ss[i].data_ptr(), out2=h_next.data_ptr(), ld_aux=ld)
-        return h_next, st
+                      aux0=zs[i].data_ptr(), aux1=ss[i].data_ptr(), out2=h_out.data_ptr(), ld_aux=ld,
+                      a_rows=F.ptr(), c_rows=F.ptr(), zero_row=pad_row)
+        if train:
+            h = K.rows(NM, ld, dev)
+            K.select_slab_rows(h.data_ptr(), hs.data_ptr(), stride, sched.sel_final.data_ptr(), NM, H, ld)
+        else:
+            h = hs[0]
+        return h, st
 
     @staticmethod
-    def backward(dh, depth, NM, H, ld, dev, st, Pr, wid, mcsr_t, WzhT, WhhT, UrT):
-        """dh: gradient w.r.t. the final h (row buffer, modified in place).
-        Returns (dzpre[T], dppre[T], dUh[T], A_r) for the weight / table gradients."""
-        T = depth
+    def backward(dh, sched, bs, NM, H, ld, dev, st, Pr, wid, mcsr_t, WzhT, WhhT, UrT, pad_row=0):
+        """dh: gradient w.r.t. the final h (row buffer indexed by message, modified in place).
+        Returns compact (dz [nE], dp [nE], du [nJ]) and A_r [NM] for the weight / table gradients."""
+        T = sched.T
         hs, zs, ps, ss, gs, ts, us = (st[k] for k in ("hs", "zs", "ps", "ss", "gs", "ts", "us"))
-        dz = torch.empty((T, NM, ld), dtype=torch.float32, device=dev)
-        dp = torch.empty_like(dz)
-        du = torch.empty_like(dz)
-        a_r = torch.zeros((NM, ld), dtype=torch.float32, device=dev)
-        ds = K.rows(NM, ld, dev)
-        dg = K.rows(NM, ld, dev)
-        dhdir = K.rows(NM, ld, dev)
+        stride = NM * ld
+        sf_p = sched.sf.data_ptr()
+        act_p = None if bs.active is None else bs.active.data_ptr()
+        dz = K.rows(max(bs.nE, 1), ld, dev)
+        dp = K.rows(max(bs.nE, 1), ld, dev)
+        du = K.rows(max(bs.nJ, 1), ld, dev)
+        a_r = K.rows(NM, ld, dev, zero=True)
+        ds, dg, dhdir = K.rows(NM, ld, dev), K.rows(NM, ld, dev), K.rows(NM, ld, dev)
         wid_p = wid.data_ptr()
-        for t in range(T - 1, 0, -1):
-            K.gru_bwd_pointwise(dh.data_ptr(), zs[t].data_ptr(), ps[t].data_ptr(), ss[t].data_ptr(),
-                                dz[t].data_ptr(), dp[t].data_ptr(), ds.data_ptr(), NM, H, ld)
+        for t in range(T - 1, -1, -1):
+            E = bs.E[t]
+            if E.n == 0:
+                break  # no gradient reaches earlier iterations
+            dz_t, dp_t = K.ptr(dz, bs.offE[t] * ld), K.ptr(dp, bs.offE[t] * ld)
+            K.gru_bwd_pointwise(dh.data_ptr(), zs.data_ptr(), ps.data_ptr(), ss.data_ptr(), stride, t, sf_p,
+                                E.ptr(), E.n, dz_t, dp_t, ds.data_ptr(), H, ld, pad_row)
+            if t == 0:
+                break
+            J = bs.J[t]
             # ds += dzpre W_z[:, H:]
-            K.gemm_nt(dz[t].data_ptr(), ld, WzhT.data_ptr(), ld, ds.data_ptr(), ld, NM, H, H,
-                      add=ds.data_ptr(), ld_add=ld)
+            K.gemm_nt(dz_t, ld, WzhT.data_ptr(), ld, ds.data_ptr(), ld, E.n, H, H, add=ds.data_ptr(), ld_add=ld,
+                      c_rows=E.ptr())
             # dg = dppre W_h[:, H:];  A_r += dg * t   (gradient reaching W_r x through the reset gate)
-            K.gemm_nt(dp[t].data_ptr(), ld, WhhT.data_ptr(), ld, dg.data_ptr(), ld, NM, H, H,
-                      mode=K.EPI_MUL_ACC, aux0=ts[t].data_ptr(), out2=a_r.data_ptr(), ld_aux=ld)
-            K.gru_bwd_gather(hs[t].data_ptr(), us[t].data_ptr(), Pr.data_ptr(), wid_p, dg.data_ptr(),
-                             ds.data_ptr(), mcsr_t.rowptr.data_ptr(), mcsr_t.col.data_ptr(),
-                             du[t].data_ptr(), dhdir.data_ptr(), NM, H, ld, nnz=mcsr_t.nnz)
-            # dh_t = dUh U_r + direct part
-            K.gemm_nt(du[t].data_ptr(), ld, UrT.data_ptr(), ld, dh.data_ptr(), ld, NM, H, H,
-                      add=dhdir.data_ptr(), ld_add=ld)
-        if T >= 1:
-            K.gru_bwd_pointwise(dh.data_ptr(), zs[0].data_ptr(), ps[0].data_ptr(), ss[0].data_ptr(),
-                                dz[0].data_ptr(), dp[0].data_ptr(), ds.data_ptr(), NM, H, ld)
+            K.gemm_nt(dp_t, ld, WhhT.data_ptr(), ld, dg.data_ptr(), ld, E.n, H, H, mode=K.EPI_MUL_ACC,
+                      aux0=ts.data_ptr(), out2=a_r.data_ptr(), ld_aux=ld, c_rows=E.ptr(), aux_sf=sf_p, aux_t=t,
+                      aux_slab_stride=stride)
+            if J.n == 0:
+                break
+            du_t = K.ptr(du, bs.offJ[t] * ld)
+            K.gru_bwd_gather(hs.data_ptr(), us.data_ptr(), stride, t, sf_p, act_p, Pr.data_ptr(), wid_p,
+                             dg.data_ptr(), ds.data_ptr(), mcsr_t.rowptr.data_ptr(), mcsr_t.col.data_ptr(),
+                             J.ptr(), J.n, du_t, dhdir.data_ptr(), H, ld, nnz=J.nnz)
+            # dh_t = dUh U_r + direct part, for the messages that were read
+            K.gemm_nt(du_t, ld, UrT.data_ptr(), ld, dh.data_ptr(), ld, J.n, H, H, add=dhdir.data_ptr(), ld_add=ld,
+                      c_rows=J.ptr())
         return dz, dp, du, a_r
 
 
@@ -143,6 +157,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         NM, B, NW = P.n_mess, P.n_trees, P.n_words
         train = any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)  # an unused output (messages in encode_latent) costs nothing
+        sched = graphprep.tree_schedule(P, depth, dense=(SCHEDULE == "dense"))
 
         # embedding rows of the words that occur in the batch            (jtnn_enc.py:27-28)
         E_p = as_row_buffer(E, H, ld)
@@ -159,8 +174,8 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         K.gemm_nt(Eu.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NW, H, H, bias=bh.detach().data_ptr())
         K.gemm_nt(Eu.data_ptr(), ld, Wox.data_ptr(), ld, Po.data_ptr(), ld, NW, H, H, bias=bout.detach().data_ptr())
 
-        h, st = _TreeGRU.forward(True, depth, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p,
-                                 bu.detach(), Whh, train)
+        h, st = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p, bu.detach(), Whh,
+                                 train)
 
         # output stage on the root nodes only                             (jtnn_enc.py:31-41)
         nsum = K.rows(B, ld, dev)
@@ -171,7 +186,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
                   ld_add=ld, add_idx=P.wid_root.data_ptr(), act=K.ACT_RELU)
         if train:
             ctx.prep, ctx.depth, ctx.H, ctx.ld = P, depth, H, ld
-            ctx.st = st
+            ctx.st, ctx.sched = st, sched
             ctx.keep = (Eu, Pr, nsum, tv, Wout, Wz, Wr, Ur_w, Wh)
             ctx.vocab = E.shape[0]
         return dense_view(tv, H), dense_view(h, H)
@@ -180,10 +195,12 @@ class _JTNNEncoderFunction(torch.autograd.Function):
     def backward(ctx, dtv, dmess):
         P, depth, H, ld = ctx.prep, ctx.depth, ctx.H, ctx.ld
         Eu, Pr, nsum, tv, Wout, Wz, Wr, Ur_w, Wh = ctx.keep
-        st = ctx.st
+        st, sched = ctx.st, ctx.sched
         dev = Eu.device
         NM, B, NW, V = P.n_mess, P.n_trees, P.n_words, ctx.vocab
         T = depth
+        # which messages carry gradient: all of them if the caller used `messages`, else those into a root
+        bs = graphprep.backward_schedule(P, sched, all_messages=dmess is not None)
 
         dWout = torch.empty((H, 2 * H), dtype=torch.float32, device=dev)
         dWz = torch.empty((H, 2 * H), dtype=torch.float32, device=dev)
@@ -206,35 +223,38 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         K.gemm_nt(dpre_root.data_ptr(), ld, WohT.data_ptr(), ld, dnsum.data_ptr(), ld, B, H, H)
         dh = K.rows(NM, ld, dev)
         if dmess is not None:
-            K.copy_rows(dmess.data_ptr() if dmess.stride(1) == 1 else dmess.contiguous().data_ptr(),
-                        dmess.stride(0) if dmess.stride(1) == 1 else H, dh.data_ptr(), ld, NM, H)
+            dm = dmess if dmess.stride(1) == 1 else dmess.contiguous()
+            K.copy_rows(dm.data_ptr(), dm.stride(0), dh.data_ptr(), ld, NM, H)
         K.csr_gather_sum(dh.data_ptr(), dnsum.data_ptr(), B, None, P.rcsr_t.rowptr.data_ptr(),
                          P.rcsr_t.col.data_ptr(), NM, H, ld, accumulate=dmess is not None, nnz=P.rcsr_t.nnz)
 
         WzhT, WhhT, UrT = _pack_weight_t(Wz, H, H), _pack_weight_t(Wh, H, H), _pack_weight_t(Ur_w, 0, H)
-        dz, dp, du, a_r = _TreeGRU.backward(dh, T, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT, WhhT, UrT)
-
-        # weight gradients of the three per-iteration GEMMs, one contraction over all iterations
-        if T >= 2:
-            Mtot = (T - 1) * NM
-            K.gemm_tn(dz[1].data_ptr(), ld, st["ss"][1].data_ptr(), ld, K.ptr(dWz, H), 2 * H, Mtot, H, H, False, dev)
-            K.gemm_tn(dp[1].data_ptr(), ld, st["gs"][1].data_ptr(), ld, K.ptr(dWh, H), 2 * H, Mtot, H, H, False, dev)
-            K.gemm_tn(du[1].data_ptr(), ld, st["hs"][1].data_ptr(), ld, dUr.data_ptr(), H, Mtot, H, H, False, dev)
-            K.colsum(du[1].data_ptr(), ld, dbu.data_ptr(), Mtot, H, False, dev)
+        if T >= 1:
+            dz, dp, du, a_r = _TreeGRU.backward(dh, sched, bs, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT,
+                                                WhhT, UrT)
+        # weight gradients of the three per-iteration GEMMs: one contraction each over every
+        # (iteration, message) pair that carried gradient, operands picked through row lists
+        if T >= 1 and bs.n_z > 0:
+            K.gemm_tn(dz.data_ptr(), ld, st["ss"].data_ptr(), ld, K.ptr(dWz, H), 2 * H, bs.n_z, H, H, False, dev,
+                      x_rows=bs.zx.data_ptr(), y_rows=bs.zy.data_ptr())
+            K.gemm_tn(dp.data_ptr(), ld, st["gs"].data_ptr(), ld, K.ptr(dWh, H), 2 * H, bs.n_z, H, H, False, dev,
+                      x_rows=bs.zx.data_ptr(), y_rows=bs.zy.data_ptr())
         else:
             dWz[:, H:].zero_()
             dWh[:, H:].zero_()
+        if T >= 1 and bs.n_u > 0:
+            K.gemm_tn(du.data_ptr(), ld, st["hs"].data_ptr(), ld, dUr.data_ptr(), H, bs.n_u, H, H, False, dev,
+                      x_rows=bs.ux.data_ptr(), y_rows=bs.uy.data_ptr())
+            K.colsum(du.data_ptr(), ld, dbu.data_ptr(), bs.nJ, H, False, dev)
+        else:
             dUr.zero_()
             dbu.zero_()
 
         # gradients of the per-word tables
         dPo = _keyed_sum(dpre_root, P.key_r_pieces, P.key_r, NW, H, ld, dev)
-        if T >= 1:
-            a_z, a_h = K.rows(NM, ld, dev), K.rows(NM, ld, dev)
-            K.slab_sum(a_z.data_ptr(), dz.data_ptr(), T, NM * ld, NM, H, ld)
-            K.slab_sum(a_h.data_ptr(), dp.data_ptr(), T, NM * ld, NM, H, ld)
-            dPz = _keyed_sum(a_z, P.key_m_pieces, P.key_m, NW, H, ld, dev)
-            dPh = _keyed_sum(a_h, P.key_m_pieces, P.key_m, NW, H, ld, dev)
+        if T >= 1 and bs.nE > 0:
+            dPz = _keyed_sum(dz, bs.key_pieces, bs.key, NW, H, ld, dev)
+            dPh = _keyed_sum(dp, bs.key_pieces, bs.key, NW, H, ld, dev)
             dPr = _keyed_sum(a_r, P.key_m_pieces, P.key_m, NW, H, ld, dev)
         else:
             dPz, dPh, dPr = (K.rows(NW, ld, dev, zero=True) for _ in range(3))
@@ -307,7 +327,10 @@ class GraphGRU(nn.Module):
             K.gemm_nt(x_p.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NM, H, H)
             K.gemm_nt(x_p.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NM, H, H,
                       bias=self.W_h.bias.data_ptr())
-            out, _ = _TreeGRU.forward(True, self.depth, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur_p,
+            trp, tcol = graphprep.transpose_csr(rp, col, NM)
+            sched = graphprep.build_tree_schedule(rp, col, trp, tcol, NM, self.depth, dev,
+                                                  dense=(SCHEDULE == "dense"))
+            out, _ = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur_p,
                                       self.U_r.bias.detach(), Whh, False)
         return dense_view(out, H)
 

@@ -109,7 +109,7 @@ def test_gemm_nt_gru_blend_and_mul_acc(K):
     K.gemm_nt(dev_rows(G, ld).data_ptr(), ld, dev_rows(W, ld).data_ptr(), ld, P.data_ptr(), ld, M, N, N,
               add=dev_rows(tab, ld).data_ptr(), ld_add=ld, add_idx=dev(idx).data_ptr(),
               mode=K.EPI_GRU_BLEND, aux0=dev_rows(z, ld).data_ptr(), aux1=dev_rows(s, ld).data_ptr(),
-              out2=Hn.data_ptr(), ld_aux=ld)
+              out2=Hn.data_ptr(), ld_aux=ld, zero_row=0)
     torch.cuda.synchronize()
     assert rel_err(P[:, :N].cpu().numpy(), p_ref) < 3e-6
     assert rel_err(Hn[:, :N].cpu().numpy(), h_ref) < 3e-6
@@ -274,11 +274,11 @@ def test_gru_kernels(K):
     i32 = lambda x: dev(np.asarray(x, dtype=np.int32))  # noqa: E731
     hd, Ud, Prd, widd, rpd, cold = dv(h), dv(Uh), dv(Pr), i32(wid), i32(rp), i32(col)
     s, g, t = (torch.empty((NM, ld), device="cuda") for _ in range(3))
-    K.gru_gate_gather(hd.data_ptr(), Ud.data_ptr(), Prd.data_ptr(), widd.data_ptr(), rpd.data_ptr(),
-                      cold.data_ptr(), s.data_ptr(), g.data_ptr(), t.data_ptr(), NM, H, ld)
+    K.gru_gate_gather(hd.data_ptr(), Ud.data_ptr(), 0, 0, None, Prd.data_ptr(), widd.data_ptr(), rpd.data_ptr(),
+                      cold.data_ptr(), None, NM, s.data_ptr(), g.data_ptr(), t.data_ptr(), H, ld)
     s2, g2 = (torch.empty((NM, ld), device="cuda") for _ in range(2))
-    K.gru_gate_gather(hd.data_ptr(), Ud.data_ptr(), Prd.data_ptr(), widd.data_ptr(), rpd.data_ptr(),
-                      cold.data_ptr(), s2.data_ptr(), g2.data_ptr(), None, NM, H, ld)
+    K.gru_gate_gather(hd.data_ptr(), Ud.data_ptr(), 0, 0, None, Prd.data_ptr(), widd.data_ptr(), rpd.data_ptr(),
+                      cold.data_ptr(), None, NM, s2.data_ptr(), g2.data_ptr(), None, H, ld)
     torch.cuda.synchronize()
     assert rel_err(s[:, :H].cpu().numpy(), s_ref) < 1e-6
     assert rel_err(g[:, :H].cpu().numpy(), g_ref) < 2e-6
@@ -287,7 +287,7 @@ def test_gru_kernels(K):
     # iteration 0
     z, p, h1 = (torch.empty((NM, ld), device="cuda") for _ in range(3))
     K.gru_iter0(dv(Pz).data_ptr(), dv(Ph).data_ptr(), widd.data_ptr(), z.data_ptr(), p.data_ptr(), h1.data_ptr(),
-                NM, H, ld)
+                NM, H, ld, 0)
     torch.cuda.synchronize()
     z_ref, p_ref = sig(Pz[wid].astype(np.float64)), np.tanh(Ph[wid].astype(np.float64))
     h_ref = z_ref * p_ref
@@ -298,8 +298,8 @@ def test_gru_kernels(K):
     dh = rs.standard_normal((NM, H)).astype(np.float32)
     zz, pp, ss = rs.rand(NM, H).astype(np.float32), np.tanh(rs.standard_normal((NM, H))).astype(np.float32), s_ref
     dz, dp, ds = (torch.empty((NM, ld), device="cuda") for _ in range(3))
-    K.gru_bwd_pointwise(dv(dh).data_ptr(), dv(zz).data_ptr(), dv(pp).data_ptr(), dv(ss).data_ptr(), dz.data_ptr(),
-                        dp.data_ptr(), ds.data_ptr(), NM, H, ld)
+    K.gru_bwd_pointwise(dv(dh).data_ptr(), dv(zz).data_ptr(), dv(pp).data_ptr(), dv(ss).data_ptr(), 0, 1, None, None,
+                        NM, dz.data_ptr(), dp.data_ptr(), ds.data_ptr(), H, ld, 0)
     torch.cuda.synchronize()
     d = dh.astype(np.float64).copy(); d[0] = 0
     assert rel_err(dz[:, :H].cpu().numpy(), d * (pp - ss) * zz * (1 - zz)) < 2e-6
@@ -318,9 +318,9 @@ def test_gru_kernels(K):
             du_ref[j] += dg[m] * r * (1 - r) * h[j]
             dh_ref[j] += dsv[m] + dg[m] * r
     du, dhd = (torch.empty((NM, ld), device="cuda") for _ in range(2))
-    K.gru_bwd_gather(hd.data_ptr(), Ud.data_ptr(), Prd.data_ptr(), widd.data_ptr(), dv(dg).data_ptr(),
-                     dv(dsv).data_ptr(), i32(trp).data_ptr(), i32(tcol).data_ptr(), du.data_ptr(), dhd.data_ptr(),
-                     NM, H, ld)
+    K.gru_bwd_gather(hd.data_ptr(), Ud.data_ptr(), 0, 0, None, None, Prd.data_ptr(), widd.data_ptr(),
+                     dv(dg).data_ptr(), dv(dsv).data_ptr(), i32(trp).data_ptr(), i32(tcol).data_ptr(), None, NM,
+                     du.data_ptr(), dhd.data_ptr(), H, ld)
     torch.cuda.synchronize()
     assert rel_err(du[:, :H].cpu().numpy(), du_ref) < 3e-6
     assert rel_err(dhd[:, :H].cpu().numpy(), dh_ref) < 3e-6
@@ -337,3 +337,74 @@ def test_row_dot(K):
               dev_rows(c, ld).data_ptr(), NC, H, ld)
     torch.cuda.synchronize()
     assert rel_err(sc.cpu().numpy(), (q[own].astype(np.float64) * c).sum(1)) < 2e-6
+
+
+def test_row_list_variants(K):
+    """Gathered A rows / scattered C rows in gemm_nt, row-pair lists in gemm_tn, active-row lists and
+    per-iteration slabs in the GRU kernels."""
+    rs = np.random.RandomState(11)
+    H, ld, NM, n = 450, 452, 300, 77
+    rows = np.sort(rs.choice(NM, size=n, replace=False)).astype(np.int32)
+    A = rs.standard_normal((NM, H)).astype(np.float32) * 0.2
+    W = rs.standard_normal((H, H)).astype(np.float32) * 0.2
+    base = rs.standard_normal((NM, H)).astype(np.float32)
+    C = dev_rows(base, ld)
+    rd = dev(rows)
+    K.gemm_nt(dev_rows(A, ld).data_ptr(), ld, dev_rows(W, ld).data_ptr(), ld, C.data_ptr(), ld, n, H, H,
+              a_rows=rd.data_ptr(), c_rows=rd.data_ptr(), add=C.data_ptr(), ld_add=ld)
+    torch.cuda.synchronize()
+    want = base.astype(np.float64).copy()
+    want[rows] += A[rows].astype(np.float64) @ W.astype(np.float64).T
+    assert rel_err(C[:, :H].cpu().numpy(), want) < 3e-6  # untouched rows keep their value exactly
+    # compact A, scattered C
+    Cc = dev_rows(base, ld)
+    K.gemm_nt(dev_rows(A[rows], ld).data_ptr(), ld, dev_rows(W, ld).data_ptr(), ld, Cc.data_ptr(), ld, n, H, H,
+              c_rows=rd.data_ptr())
+    torch.cuda.synchronize()
+    want2 = base.astype(np.float64).copy()
+    want2[rows] = A[rows].astype(np.float64) @ W.astype(np.float64).T
+    assert rel_err(Cc[:, :H].cpu().numpy(), want2) < 3e-6
+    # gemm_tn over row pairs
+    M = 1000
+    xr = rs.randint(0, NM, size=M).astype(np.int32)
+    yr = rs.randint(0, NM, size=M).astype(np.int32)
+    Y = rs.standard_normal((NM, H)).astype(np.float32)
+    dW = torch.zeros((H, H), device="cuda")
+    K.gemm_tn(dev_rows(A, ld).data_ptr(), ld, dev_rows(Y, ld).data_ptr(), ld, dW.data_ptr(), H, M, H, H, False, "cuda",
+              x_rows=dev(xr).data_ptr(), y_rows=dev(yr).data_ptr())
+    torch.cuda.synchronize()
+    ref = A[xr].astype(np.float64).T @ Y[yr].astype(np.float64)
+    assert rel_err(dW.cpu().numpy(), ref) < 3e-6
+    # gate gather on a row list with slabs: neighbour j is read from slab min(t, sf[j])
+    T_, V = 4, 9
+    hs = rs.standard_normal((T_, NM, H)).astype(np.float32) * 0.5
+    us = rs.standard_normal((T_, NM, H)).astype(np.float32)
+    sf = rs.randint(1, T_ + 2, size=NM).astype(np.int32)
+    Pr = rs.standard_normal((V, H)).astype(np.float32)
+    wid = rs.randint(0, V, size=NM).astype(np.int32)
+    rp, col = random_csr(rs, NM, NM, 4)
+    t_iter = 2
+    hsd = keep(torch.zeros((T_, NM, ld), device="cuda")); hsd[:, :, :H] = torch.from_numpy(hs).cuda()
+    usd = keep(torch.zeros((T_, NM, ld), device="cuda")); usd[:, :, :H] = torch.from_numpy(us).cuda()
+    s0 = rs.standard_normal((NM, H)).astype(np.float32)
+    sd, gd, td = dev_rows(s0, ld), dev_rows(s0, ld), dev_rows(s0, ld)
+    K.gru_gate_gather(hsd.data_ptr(), usd.data_ptr(), NM * ld, t_iter, dev(sf).data_ptr(), dev_rows(Pr, ld).data_ptr(),
+                      dev(wid).data_ptr(), dev(rp.astype(np.int32)).data_ptr(), dev(col.astype(np.int32)).data_ptr(),
+                      rd.data_ptr(), n, sd.data_ptr(), gd.data_ptr(), td.data_ptr(), H, ld)
+    torch.cuda.synchronize()
+    sig = lambda v: 1 / (1 + np.exp(-v))  # noqa: E731
+    s_ref, g_ref = s0.astype(np.float64).copy(), s0.astype(np.float64).copy()
+    for m in rows:
+        s_ref[m] = 0; g_ref[m] = 0
+        for e in range(rp[m], rp[m + 1]):
+            j = col[e]; tau = min(t_iter, sf[j])
+            r = sig(Pr[wid[m]].astype(np.float64) + us[tau, j])
+            s_ref[m] += hs[tau, j]; g_ref[m] += r * hs[tau, j]
+    assert rel_err(sd[:, :H].cpu().numpy(), s_ref) < 2e-6
+    assert rel_err(gd[:, :H].cpu().numpy(), g_ref) < 2e-6
+    # final-value collection
+    sel = np.minimum(sf, T_ - 1).astype(np.int32)
+    out = torch.empty((NM, ld), device="cuda")
+    K.select_slab_rows(out.data_ptr(), hsd.data_ptr(), NM * ld, dev(sel).data_ptr(), NM, H, ld)
+    torch.cuda.synchronize()
+    assert np.array_equal(out[:, :H].cpu().numpy(), hs[sel, np.arange(NM)])
