@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=385)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="print a per-shape GEMM table to stderr")
     args = ap.parse_args()
 
     from fast_jtnn_hip import _capi as K
@@ -155,6 +156,10 @@ def main():
         # one extra, untimed step with every C-ABI launch bracketed by HIP events on its stream
         with K.KernelTimer() as kt:
             step()
+        if args.detail:
+            for (name, tag), d in sorted(kt.detail().items(), key=lambda kv: -kv[1]["ms"])[:40]:
+                tf = d["flops"] / max(d["ms"], 1e-9) / 1e9
+                print("%-18s %-34s x%-3d %8.3f ms %7.1f TF" % (name, tag, d["launches"], d["ms"], tf), file=sys.stderr)
         kernels = []
         for name, d in kt.summary().items():
             sec = d["ms"] * 1e-3

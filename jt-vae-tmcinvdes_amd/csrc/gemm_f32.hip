@@ -89,6 +89,62 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// Per-output-row state of the epilogue, shared by both NT kernels.
+struct EpiRow {
+  int m;                 // id of the output row
+  float* c_row;
+  const float* add_row;  // nullable
+  const float* mul_row;  // MUL_ACC multiplier row, nullable
+  size_t aux_off;
+};
+
+template <int MODE>
+__device__ __forceinline__ EpiRow epi_row(const NtArgs& a, int i) {
+  const jtvae_epilogue_t& e = a.e;
+  EpiRow R;
+  R.m = e.c_rows ? e.c_rows[i] : i;
+  R.c_row = a.C + (size_t)R.m * a.ldc;
+  R.add_row = e.add ? e.add + (size_t)(e.add_idx ? e.add_idx[R.m] : R.m) * e.ld_add : nullptr;
+  R.aux_off = (size_t)R.m * e.ld_aux;
+  R.mul_row = nullptr;
+  if (MODE == JTVAE_EPI_MUL_ACC) {
+    if (e.aux_sf) {
+      const int tau = min(e.aux_t, e.aux_sf[R.m] - 1);
+      if (tau > 0) R.mul_row = e.aux0 + (size_t)tau * e.aux_slab_stride + R.aux_off;  // slab 0 is all zero
+    } else {
+      R.mul_row = e.aux0 + R.aux_off;
+    }
+  }
+  return R;
+}
+
+template <int MODE>
+__device__ __forceinline__ void epi_store(const NtArgs& a, const EpiRow& R, int n, float v) {
+  const jtvae_epilogue_t& e = a.e;
+  if (n >= a.N) {
+    // padding columns of the outputs are defined as zero
+    if (n < a.ldc) R.c_row[n] = 0.f;
+    if (MODE == JTVAE_EPI_PLAIN && e.pre_out && n < e.ld_pre) e.pre_out[(size_t)R.m * e.ld_pre + n] = 0.f;
+    if (MODE == JTVAE_EPI_GRU_BLEND && n < e.ld_aux) e.out2[R.aux_off + n] = 0.f;
+    return;
+  }
+  if (e.bias) v += e.bias[n];
+  if (R.add_row) v += R.add_row[n];
+  if (MODE == JTVAE_EPI_PLAIN) {
+    if (e.pre_out) e.pre_out[(size_t)R.m * e.ld_pre + n] = v;
+    R.c_row[n] = act_apply(v, e.act);
+  } else if (MODE == JTVAE_EPI_GRU_BLEND) {
+    const float p = tanhf(v);
+    const float z = e.aux0[R.aux_off + n];
+    const float s = e.aux1[R.aux_off + n];
+    R.c_row[n] = p;
+    e.out2[R.aux_off + n] = (R.m == e.zero_row) ? 0.f : fmaf(z, p - s, s);  // (1-z)s + zp
+  } else {  // JTVAE_EPI_MUL_ACC
+    R.c_row[n] = v;
+    if (R.mul_row) e.out2[R.aux_off + n] = fmaf(v, R.mul_row[n], e.out2[R.aux_off + n]);
+  }
+}
+
 template <bool VEC, int MODE>
 __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   __shared__ __attribute__((aligned(16))) float As[NT_BM * NT_LDS];
@@ -186,46 +242,87 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   for (int r = 0; r < 16; ++r) {
     const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (i >= a.M) continue;
-    const int m = e.c_rows ? e.c_rows[i] : i;  // id of the output row
-    float* c_row = a.C + (size_t)m * a.ldc;
-    const float* add_row = nullptr;
-    if (e.add) add_row = e.add + (size_t)(e.add_idx ? e.add_idx[m] : m) * e.ld_add;
-    const size_t aux_off = (size_t)m * e.ld_aux;
-    const float* mul_row = nullptr;  // MUL_ACC multiplier row, possibly out of a per-iteration slab
-    if (MODE == JTVAE_EPI_MUL_ACC) {
-      if (e.aux_sf) {
-        const int tau = min(e.aux_t, e.aux_sf[m] - 1);
-        if (tau > 0) mul_row = e.aux0 + (size_t)tau * e.aux_slab_stride + aux_off;  // slab 0 is all zero
-      } else {
-        mul_row = e.aux0 + aux_off;
-      }
-    }
+    const EpiRow R = epi_row<MODE>(a, i);
 #pragma unroll
-    for (int t = 0; t < NT_NT; ++t) {
-      const int n = n0 + 32 * t + col_in_tile;
-      if (n >= a.N) {
-        // padding columns of the outputs are defined as zero
-        if (n < a.ldc) c_row[n] = 0.f;
-        if (MODE == JTVAE_EPI_PLAIN && e.pre_out && n < e.ld_pre) e.pre_out[(size_t)m * e.ld_pre + n] = 0.f;
-        if (MODE == JTVAE_EPI_GRU_BLEND && n < e.ld_aux) e.out2[aux_off + n] = 0.f;
-        continue;
-      }
-      float v = acc[t][r];
-      if (e.bias) v += e.bias[n];
-      if (add_row) v += add_row[n];
-      if (MODE == JTVAE_EPI_PLAIN) {
-        if (e.pre_out) e.pre_out[(size_t)m * e.ld_pre + n] = v;
-        c_row[n] = act_apply(v, e.act);
-      } else if (MODE == JTVAE_EPI_GRU_BLEND) {
-        const float p = tanhf(v);
-        const float z = e.aux0[aux_off + n];
-        const float s = e.aux1[aux_off + n];
-        c_row[n] = p;
-        e.out2[aux_off + n] = (m == e.zero_row) ? 0.f : fmaf(z, p - s, s);  // (1-z)s + zp
-      } else {  // JTVAE_EPI_MUL_ACC
-        c_row[n] = v;
-        if (mul_row) e.out2[aux_off + n] = fmaf(v, mul_row[n], e.out2[aux_off + n]);
-      }
+    for (int t = 0; t < NT_NT; ++t) epi_store<MODE>(a, R, n0 + 32 * t + col_in_tile, acc[t][r]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Small-M variant.  The tail iterations of the tree GRU touch a few to a few hundred rows; with
+// the tiled kernel such a launch is one or two blocks walking 15 dependent K tiles (load ->
+// LDS -> MFMA -> barrier), ~45 us of pure latency.  Here one block owns a 32 x 32 output tile,
+// pulls the whole K extent of its A and W rows into LDS with every load in flight at once,
+// splits K over its four waves and adds the four partial tiles through LDS: one memory round
+// trip instead of fifteen.  K <= SM_KMAX, aligned operands.
+constexpr int SM_KMAX = 456;
+constexpr int SM_LD = 460;                 // LDS row stride (floats): 115 float4, odd -> conflict-free b128 reads
+constexpr int SM_C4 = SM_KMAX / 4;         // float4 per staged row
+constexpr int SM_PER_THREAD = (32 * SM_C4 + 255) / 256;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void gemm_nt_small_kernel(NtArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * 32 * SM_LD];  // 115 KiB: one block per CU
+  float* As = sm;
+  float* Ws = sm + 32 * SM_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = (blockIdx.x / a.n_tiles_n) * 32;
+  const int n0 = (blockIdx.x % a.n_tiles_n) * 32;
+  const jtvae_epilogue_t& e = a.e;
+  const int c4n = (a.K + 3) >> 2;  // float4 per row that hold data
+
+  float4 va[SM_PER_THREAD], vw[SM_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < SM_PER_THREAD; ++u) {
+    const int idx = tid + 256 * u;
+    const int row = min(idx / SM_C4, 31), c4 = idx % SM_C4;
+    int m = min(m0 + row, a.M - 1);
+    if (e.a_rows) m = e.a_rows[m];
+    const int n = min(n0 + row, a.N - 1);
+    const int k = c4 < c4n ? 4 * c4 : 0;
+    va[u] = *reinterpret_cast<const float4*>(a.A + (size_t)m * a.lda + k);
+    vw[u] = *reinterpret_cast<const float4*>(a.W + (size_t)n * a.ldw + k);
+  }
+#pragma unroll
+  for (int u = 0; u < SM_PER_THREAD; ++u) {
+    const int idx = tid + 256 * u;
+    if (idx < 32 * SM_C4) {
+      const int row = idx / SM_C4, c4 = idx % SM_C4;
+      const bool in_k = c4 < c4n;
+      *reinterpret_cast<float4*>(&As[row * SM_LD + 4 * c4]) = mask4(va[u], in_k && m0 + row < a.M, 4 * c4, a.K);
+      *reinterpret_cast<float4*>(&Ws[row * SM_LD + 4 * c4]) = mask4(vw[u], in_k && n0 + row < a.N, 4 * c4, a.K);
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* a_frag = &As[(lane & 31) * SM_LD + 4 * (lane >> 5)];
+  const float* w_frag = &Ws[(lane & 31) * SM_LD + 4 * (lane >> 5)];
+  const int groups = (a.K + 7) >> 3;
+  for (int g = wave; g < groups; g += 4) {
+    const float4 av = *reinterpret_cast<const float4*>(a_frag + 8 * g);
+    const float4 bv = *reinterpret_cast<const float4*>(w_frag + 8 * g);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+  }
+  __syncthreads();  // operands no longer needed: reuse their LDS for the four partial tiles
+  float* red = sm + wave * (32 * 33);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[r];
+  __syncthreads();
+  const int row = tid >> 3, nq = (tid & 7) * 4;
+  if (m0 + row < a.M) {
+    const EpiRow R = epi_row<MODE>(a, m0 + row);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = row * 33 + nq + j;
+      // fixed order: wave 0 + wave 1 + wave 2 + wave 3
+      const float v = ((sm[o] + sm[o + 32 * 33]) + sm[o + 2 * 32 * 33]) + sm[o + 3 * 32 * 33];
+      epi_store<MODE>(a, R, n0 + nq + j, v);
     }
   }
 }
@@ -421,6 +518,23 @@ inline TnPlan tn_plan(int M, int N, int K) {
   return p;
 }
 
+constexpr int SM_MAX_ROWS = 512;  // above this the tiled kernel fills the chip anyway
+
+void launch_nt_small(NtArgs a, hipStream_t s) {
+  a.n_tiles_n = (a.N + 31) / 32;
+  const int blocks = ((a.M + 31) / 32) * a.n_tiles_n;
+  switch (a.e.mode) {
+    case JTVAE_EPI_GRU_BLEND:
+      hipLaunchKernelGGL((gemm_nt_small_kernel<JTVAE_EPI_GRU_BLEND>), dim3(blocks), dim3(256), 0, s, a);
+      break;
+    case JTVAE_EPI_MUL_ACC:
+      hipLaunchKernelGGL((gemm_nt_small_kernel<JTVAE_EPI_MUL_ACC>), dim3(blocks), dim3(256), 0, s, a);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_nt_small_kernel<JTVAE_EPI_PLAIN>), dim3(blocks), dim3(256), 0, s, a);
+  }
+}
+
 template <bool VEC>
 void launch_nt(const NtArgs& a, hipStream_t s) {
   switch (a.e.mode) {
@@ -466,7 +580,9 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
   a.n_blocks = tiles_m * a.n_tiles_n;
   const bool vec = aligned16(A, lda) && aligned16(W, ldw);
   hipStream_t s = (hipStream_t)stream;
-  if (vec)
+  if (vec && M <= SM_MAX_ROWS && K <= SM_KMAX)
+    launch_nt_small(a, s);
+  else if (vec)
     launch_nt<true>(a, s);
   else
     launch_nt<false>(a, s);

@@ -156,7 +156,7 @@ class KernelTimer:
         """kernel -> dict(launches, ms, bytes, flops); synchronises once."""
         torch.cuda.synchronize()
         out = OrderedDict()
-        for name, nbytes, flops, e0, e1 in self.records:
+        for name, nbytes, flops, e0, e1, _tag in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0, flops=0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -164,8 +164,20 @@ class KernelTimer:
             d["flops"] += flops
         return out
 
+    def detail(self):
+        """(kernel, shape tag) -> dict(launches, ms, bytes, flops)."""
+        torch.cuda.synchronize()
+        out = OrderedDict()
+        for name, nbytes, flops, e0, e1, tag in self.records:
+            d = out.setdefault((name, tag), dict(launches=0, ms=0.0, bytes=0, flops=0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nbytes
+            d["flops"] += flops
+        return out
 
-def _run(name, fn, args, nbytes=0, flops=0):
+
+def _run(name, fn, args, nbytes=0, flops=0, tag=""):
     t = KernelTimer.active
     if t is None:
         check(fn(*args), name)
@@ -175,7 +187,7 @@ def _run(name, fn, args, nbytes=0, flops=0):
     e0.record()
     rc = fn(*args)
     e1.record()
-    t.records.append((name, int(nbytes), int(flops), e0, e1))
+    t.records.append((name, int(nbytes), int(flops), e0, e1, tag))
     check(rc, name)
 
 
@@ -191,7 +203,8 @@ def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0
                  a_rows, c_rows, zero_row, aux_sf, aux_t, aux_slab_stride)
     extra = (1 if add else 0) + (1 if pre_out else 0) + {EPI_PLAIN: 0, EPI_GRU_BLEND: 3, EPI_MUL_ACC: 3}[mode]
     _run("gemm_nt", lib.jtvae_gemm_nt, (A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()),
-         nbytes=4 * (M * K + N * K + M * N * (1 + extra)), flops=2 * M * N * K)
+         nbytes=4 * (M * K + N * K + M * N * (1 + extra)), flops=2 * M * N * K,
+         tag="M=%d N=%d K=%d mode=%d" % (M, N, K, mode))
 
 
 def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device, x_rows=None, y_rows=None):
@@ -199,7 +212,7 @@ def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device, x_rows=None, 
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
     _run("gemm_tn", lib.jtvae_gemm_tn, (X, ldx, x_rows, Y, ldy, y_rows, dW, lddw, M, N, K, int(accumulate),
                                         ws.data_ptr(), nbytes, stream_ptr()),
-         nbytes=4 * (M * N + M * K + N * K), flops=2 * M * N * K)
+         nbytes=4 * (M * N + M * K + N * K), flops=2 * M * N * K, tag="M=%d N=%d K=%d" % (M, N, K))
 
 
 def colsum(X, ldx, out, M, N, accumulate, device):
