@@ -52,6 +52,7 @@ struct NtArgs {
   int M, N, K;
   int n_tiles_n;
   int n_blocks;
+  int evec;  // epilogue operands are float4-addressable
   jtvae_epilogue_t e;
 };
 
@@ -89,13 +90,13 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-// Per-output-row state of the epilogue, shared by both NT kernels.
+// Per-output-row state of the epilogue, shared by both NT kernels: three integers per row, so
+// that a lane can hold several rows without crowding the accumulators out of the register file;
+// the row pointers are rebuilt from them where they are used.
 struct EpiRow {
-  int m;                 // id of the output row
-  float* c_row;
-  const float* add_row;  // nullable
-  const float* mul_row;  // MUL_ACC multiplier row, nullable
-  size_t aux_off;
+  int m;      // id of the output row
+  int add_m;  // row of the add operand
+  int tau;    // MUL_ACC: slab of the multiplier row, -1 = no multiplier (nothing to accumulate)
 };
 
 template <int MODE>
@@ -103,52 +104,153 @@ __device__ __forceinline__ EpiRow epi_row(const NtArgs& a, int i) {
   const jtvae_epilogue_t& e = a.e;
   EpiRow R;
   R.m = e.c_rows ? e.c_rows[i] : i;
-  R.c_row = a.C + (size_t)R.m * a.ldc;
-  R.add_row = e.add ? e.add + (size_t)(e.add_idx ? e.add_idx[R.m] : R.m) * e.ld_add : nullptr;
-  R.aux_off = (size_t)R.m * e.ld_aux;
-  R.mul_row = nullptr;
-  if (MODE == JTVAE_EPI_MUL_ACC) {
-    if (e.aux_sf) {
-      const int tau = min(e.aux_t, e.aux_sf[R.m] - 1);
-      if (tau > 0) R.mul_row = e.aux0 + (size_t)tau * e.aux_slab_stride + R.aux_off;  // slab 0 is all zero
-    } else {
-      R.mul_row = e.aux0 + R.aux_off;
-    }
+  R.add_m = (e.add && e.add_idx) ? e.add_idx[R.m] : R.m;
+  R.tau = 0;
+  if (MODE == JTVAE_EPI_MUL_ACC && e.aux_sf) {
+    R.tau = min(e.aux_t, e.aux_sf[R.m] - 1);
+    if (R.tau <= 0) R.tau = -1;  // slab 0 is all zero
   }
   return R;
+}
+__device__ __forceinline__ float* epi_c_row(const NtArgs& a, const EpiRow& R) { return a.C + (size_t)R.m * a.ldc; }
+__device__ __forceinline__ const float* epi_add_row(const NtArgs& a, const EpiRow& R) {
+  return a.e.add ? a.e.add + (size_t)R.add_m * a.e.ld_add : nullptr;
+}
+__device__ __forceinline__ size_t epi_aux_off(const NtArgs& a, const EpiRow& R) { return (size_t)R.m * a.e.ld_aux; }
+__device__ __forceinline__ const float* epi_mul_row(const NtArgs& a, const EpiRow& R) {
+  return R.tau < 0 ? nullptr : a.e.aux0 + (size_t)R.tau * a.e.aux_slab_stride + epi_aux_off(a, R);
 }
 
 template <int MODE>
 __device__ __forceinline__ void epi_store(const NtArgs& a, const EpiRow& R, int n, float v) {
   const jtvae_epilogue_t& e = a.e;
+  float* c_row = epi_c_row(a, R);
+  const size_t aux_off = epi_aux_off(a, R);
   if (n >= a.N) {
     // padding columns of the outputs are defined as zero
-    if (n < a.ldc) R.c_row[n] = 0.f;
+    if (n < a.ldc) c_row[n] = 0.f;
     if (MODE == JTVAE_EPI_PLAIN && e.pre_out && n < e.ld_pre) e.pre_out[(size_t)R.m * e.ld_pre + n] = 0.f;
-    if (MODE == JTVAE_EPI_GRU_BLEND && n < e.ld_aux) e.out2[R.aux_off + n] = 0.f;
+    if (MODE == JTVAE_EPI_GRU_BLEND && n < e.ld_aux) e.out2[aux_off + n] = 0.f;
     return;
   }
   if (e.bias) v += e.bias[n];
-  if (R.add_row) v += R.add_row[n];
+  if (e.add) v += epi_add_row(a, R)[n];
   if (MODE == JTVAE_EPI_PLAIN) {
     if (e.pre_out) e.pre_out[(size_t)R.m * e.ld_pre + n] = v;
-    R.c_row[n] = act_apply(v, e.act);
+    c_row[n] = act_apply(v, e.act);
   } else if (MODE == JTVAE_EPI_GRU_BLEND) {
     const float p = tanhf(v);
-    const float z = e.aux0[R.aux_off + n];
-    const float s = e.aux1[R.aux_off + n];
-    R.c_row[n] = p;
-    e.out2[R.aux_off + n] = (R.m == e.zero_row) ? 0.f : fmaf(z, p - s, s);  // (1-z)s + zp
+    const float z = e.aux0[aux_off + n];
+    const float s = e.aux1[aux_off + n];
+    c_row[n] = p;
+    e.out2[aux_off + n] = (R.m == e.zero_row) ? 0.f : fmaf(z, p - s, s);  // (1-z)s + zp
   } else {  // JTVAE_EPI_MUL_ACC
-    R.c_row[n] = v;
-    if (R.mul_row) e.out2[R.aux_off + n] = fmaf(v, R.mul_row[n], e.out2[R.aux_off + n]);
+    c_row[n] = v;
+    const float* mul_row = epi_mul_row(a, R);
+    if (mul_row) e.out2[aux_off + n] = fmaf(v, mul_row[n], e.out2[aux_off + n]);
   }
 }
 
-template <bool VEC, int MODE>
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// zero the components at or past column count nv
+__device__ __forceinline__ float4 keep_cols(float4 v, int nv) {
+  v.x = nv > 0 ? v.x : 0.f;
+  v.y = nv > 1 ? v.y : 0.f;
+  v.z = nv > 2 ? v.z : 0.f;
+  v.w = nv > 3 ? v.w : 0.f;
+  return v;
+}
+
+// Vector form of the epilogue: J output rows x four consecutive columns [n, n+4) per lane.
+// Every operand row is read and written as one float4 and all reads are issued before the
+// first write, so the J rows' memory round trips overlap.  Needs 16-byte aligned operands
+// (n % 4 == 0, leading dimensions % 4 == 0); the arithmetic and its order are those of epi_store.
+template <int MODE, int J>
+__device__ __forceinline__ void epi_store_vec(const NtArgs& a, const EpiRow (&R)[J], const bool (&ok)[J], int n,
+                                              const float4 (&v)[J]) {
+  const jtvae_epilogue_t& e = a.e;
+  const int nv = a.N - n;  // columns of this float4 inside the matrix; <= 0: padding only
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e.bias) {
+    b4.x = nv > 0 ? e.bias[n] : 0.f;
+    b4.y = nv > 1 ? e.bias[n + 1] : 0.f;
+    b4.z = nv > 2 ? e.bias[n + 2] : 0.f;
+    b4.w = nv > 3 ? e.bias[n + 3] : 0.f;
+  }
+  const bool c_in = n < a.ldc;
+  const bool aux_in = n < e.ld_aux;
+  float4 add4[J], x0[J], x1[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    add4[j] = x0[j] = x1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!ok[j]) continue;
+    if (e.add && n < e.ld_add) add4[j] = ld4(epi_add_row(a, R[j]) + n);
+    if (MODE == JTVAE_EPI_GRU_BLEND && aux_in) {
+      x0[j] = ld4(e.aux0 + epi_aux_off(a, R[j]) + n);
+      x1[j] = ld4(e.aux1 + epi_aux_off(a, R[j]) + n);
+    }
+    if (MODE == JTVAE_EPI_MUL_ACC && aux_in && R[j].tau >= 0) {
+      x0[j] = ld4(epi_mul_row(a, R[j]) + n);
+      x1[j] = ld4(e.out2 + epi_aux_off(a, R[j]) + n);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    if (!ok[j]) continue;
+    float4 x = v[j];
+    x.x = (x.x + b4.x) + add4[j].x;
+    x.y = (x.y + b4.y) + add4[j].y;
+    x.z = (x.z + b4.z) + add4[j].z;
+    x.w = (x.w + b4.w) + add4[j].w;
+    x = keep_cols(x, nv);
+    if (MODE == JTVAE_EPI_PLAIN) {
+      if (e.pre_out && n < e.ld_pre) st4(e.pre_out + (size_t)R[j].m * e.ld_pre + n, x);
+      float4 y;
+      y.x = act_apply(x.x, e.act);
+      y.y = act_apply(x.y, e.act);
+      y.z = act_apply(x.z, e.act);
+      y.w = act_apply(x.w, e.act);
+      if (c_in) st4(epi_c_row(a, R[j]) + n, keep_cols(y, nv));
+    } else if (MODE == JTVAE_EPI_GRU_BLEND) {
+      float4 pp;
+      pp.x = tanhf(x.x);
+      pp.y = tanhf(x.y);
+      pp.z = tanhf(x.z);
+      pp.w = tanhf(x.w);
+      if (c_in) st4(epi_c_row(a, R[j]) + n, pp);  // tanh(0) = 0 keeps the padding columns zero
+      if (aux_in) {
+        float4 h;
+        h.x = fmaf(x0[j].x, pp.x - x1[j].x, x1[j].x);  // (1-z)s + zp
+        h.y = fmaf(x0[j].y, pp.y - x1[j].y, x1[j].y);
+        h.z = fmaf(x0[j].z, pp.z - x1[j].z, x1[j].z);
+        h.w = fmaf(x0[j].w, pp.w - x1[j].w, x1[j].w);
+        if (R[j].m == e.zero_row) h = make_float4(0.f, 0.f, 0.f, 0.f);
+        st4(e.out2 + epi_aux_off(a, R[j]) + n, keep_cols(h, nv));
+      }
+    } else {  // JTVAE_EPI_MUL_ACC
+      if (c_in) st4(epi_c_row(a, R[j]) + n, x);
+      if (aux_in && R[j].tau >= 0) {
+        float4 o;
+        o.x = fmaf(x.x, x0[j].x, x1[j].x);
+        o.y = fmaf(x.y, x0[j].y, x1[j].y);
+        o.z = fmaf(x.z, x0[j].z, x1[j].z);
+        o.w = fmaf(x.w, x0[j].w, x1[j].w);
+        st4(e.out2 + epi_aux_off(a, R[j]) + n, o);
+      }
+    }
+  }
+}
+
+constexpr int NT_EPI_LD = 40;  // LDS row stride of a wave's 32 x 32 staging tile: the two half-waves
+                               // (rows r and r + 4) land in disjoint bank halves
+
+template <bool VEC, int MODE, bool EVEC>
 __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
-  __shared__ __attribute__((aligned(16))) float As[NT_BM * NT_LDS];
-  __shared__ __attribute__((aligned(16))) float Bs[NT_BN * NT_LDS];
+  __shared__ __attribute__((aligned(16))) float smem[(NT_BM + NT_BN) * NT_LDS];
+  static_assert(4 * 32 * NT_EPI_LD <= (NT_BM + NT_BN) * NT_LDS, "epilogue staging must fit the operand tiles");
+  float* As = smem;
+  float* Bs = smem + NT_BM * NT_LDS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -237,14 +339,50 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   }
 
   // epilogue: accumulator register r of lane l is C[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31]
-  const int col_in_tile = lane & 31;
+  if (EVEC) {
+    // Turn each 32 x 32 accumulator through the wave's own LDS patch (the operand tiles are dead
+    // after the loop's last barrier) so that a lane ends up with float4s along the rows: the
+    // epilogue operands and results then move as 16-byte accesses, 128 contiguous bytes per
+    // eight lanes.  A wave's LDS instructions execute in order: no barrier is needed.
+    float* stage = smem + wave * (32 * NT_EPI_LD);
+    EpiRow R[4];
+    bool ok[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (i >= a.M) continue;
-    const EpiRow R = epi_row<MODE>(a, i);
+    for (int j = 0; j < 4; ++j) {
+      const int i = m0 + wave * 32 + (lane >> 3) + 8 * j;
+      ok[j] = i < a.M;
+      R[j] = epi_row<MODE>(a, ok[j] ? i : 0);
+    }
 #pragma unroll
-    for (int t = 0; t < NT_NT; ++t) epi_store<MODE>(a, R, n0 + 32 * t + col_in_tile, acc[t][r]);
+    for (int t = 0; t < NT_NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * NT_EPI_LD + (lane & 31)] = acc[t][r];
+      __builtin_amdgcn_wave_barrier();
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = ld4(&stage[((lane >> 3) + 8 * j) * NT_EPI_LD + 4 * (lane & 7)]);
+      __builtin_amdgcn_wave_barrier();
+      // two rows at a time: their operand reads overlap, and the register footprint stays under
+      // the 128-VGPR budget of four resident blocks
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const EpiRow R2[2] = {R[j], R[j + 1]};
+        const bool ok2[2] = {ok[j], ok[j + 1]};
+        const float4 v2[2] = {v[j], v[j + 1]};
+        epi_store_vec<MODE, 2>(a, R2, ok2, n0 + 32 * t + 4 * (lane & 7), v2);
+      }
+    }
+  } else {
+    const int col_in_tile = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (i >= a.M) continue;
+      const EpiRow R = epi_row<MODE>(a, i);
+#pragma unroll
+      for (int t = 0; t < NT_NT; ++t) epi_store<MODE>(a, R, n0 + 32 * t + col_in_tile, acc[t][r]);
+    }
   }
 }
 
@@ -317,12 +455,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_small_kernel(NtArgs a) {
   const int row = tid >> 3, nq = (tid & 7) * 4;
   if (m0 + row < a.M) {
     const EpiRow R = epi_row<MODE>(a, m0 + row);
+    float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int o = row * 33 + nq + j;
       // fixed order: wave 0 + wave 1 + wave 2 + wave 3
-      const float v = ((sm[o] + sm[o + 32 * 33]) + sm[o + 2 * 32 * 33]) + sm[o + 3 * 32 * 33];
-      epi_store<MODE>(a, R, n0 + nq + j, v);
+      v[j] = ((sm[o] + sm[o + 32 * 33]) + sm[o + 2 * 32 * 33]) + sm[o + 3 * 32 * 33];
+    }
+    if (a.evec) {
+      const EpiRow R1[1] = {R};
+      const bool ok1[1] = {true};
+      const float4 v1[1] = {make_float4(v[0], v[1], v[2], v[3])};
+      epi_store_vec<MODE, 1>(a, R1, ok1, n0 + nq, v1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) epi_store<MODE>(a, R, n0 + nq + j, v[j]);
     }
   }
 }
@@ -535,18 +682,32 @@ void launch_nt_small(NtArgs a, hipStream_t s) {
   }
 }
 
-template <bool VEC>
+template <bool VEC, bool EVEC>
 void launch_nt(const NtArgs& a, hipStream_t s) {
   switch (a.e.mode) {
     case JTVAE_EPI_GRU_BLEND:
-      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_GRU_BLEND>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_GRU_BLEND, EVEC>), dim3(a.n_blocks), dim3(256), 0, s, a);
       break;
     case JTVAE_EPI_MUL_ACC:
-      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_MUL_ACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_MUL_ACC, EVEC>), dim3(a.n_blocks), dim3(256), 0, s, a);
       break;
     default:
-      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_PLAIN>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_PLAIN, EVEC>), dim3(a.n_blocks), dim3(256), 0, s, a);
   }
+}
+
+// every row buffer the epilogue touches can be accessed as float4 at columns n % 4 == 0
+bool epilogue_aligned(const NtArgs& a) {
+  const jtvae_epilogue_t& e = a.e;
+  if (!aligned16(a.C, a.ldc)) return false;
+  if (e.add && !aligned16(e.add, e.ld_add)) return false;
+  if (e.pre_out && !aligned16(e.pre_out, e.ld_pre)) return false;
+  if (e.mode != JTVAE_EPI_PLAIN) {
+    if (!aligned16(e.aux0, e.ld_aux) || !aligned16(e.out2, e.ld_aux)) return false;
+    if (e.mode == JTVAE_EPI_GRU_BLEND && !aligned16(e.aux1, e.ld_aux)) return false;
+    if (e.aux_sf && (e.aux_slab_stride & 3)) return false;
+  }
+  return true;
 }
 
 }  // namespace
@@ -579,13 +740,16 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
   a.n_tiles_n = (N + NT_BN - 1) / NT_BN;
   a.n_blocks = tiles_m * a.n_tiles_n;
   const bool vec = aligned16(A, lda) && aligned16(W, ldw);
+  a.evec = epilogue_aligned(a) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (vec && M <= SM_MAX_ROWS && K <= SM_KMAX)
     launch_nt_small(a, s);
+  else if (vec && a.evec)
+    launch_nt<true, true>(a, s);
   else if (vec)
-    launch_nt<true>(a, s);
+    launch_nt<true, false>(a, s);
   else
-    launch_nt<false>(a, s);
+    launch_nt<false, false>(a, s);
   return launch_status();
 }
 
