@@ -27,6 +27,30 @@ using namespace jtvae;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Optional in-kernel timeline of the tiled NT kernel (builds with -DJTVAE_GEMM_TRACE only): lane 0
+// of every wave stamps the shader clock at the phase boundaries of its K loop into a buffer the
+// tracing harness reads back.  Product builds compile the marks away.
+#ifdef JTVAE_GEMM_TRACE
+extern "C" __device__ unsigned long long* jtvae_trace_buf = nullptr;  // [blocks*4][JTVAE_TRACE_SLOTS]
+#define JTVAE_TRACE_SLOTS 96
+#define TRACE_MARK(slot)                                                                              \
+  do {                                                                                                \
+    if ((threadIdx.x & 63) == 0 && jtvae_trace_buf && (slot) < JTVAE_TRACE_SLOTS)                      \
+      jtvae_trace_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * JTVAE_TRACE_SLOTS + (slot)] =   \
+          __builtin_readcyclecounter();                                                               \
+  } while (0)
+#define TRACE_HWID(slot)                                                                              \
+  do {                                                                                                \
+    if ((threadIdx.x & 63) == 0 && jtvae_trace_buf)                                                    \
+      jtvae_trace_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * JTVAE_TRACE_SLOTS + (slot)] =   \
+          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |                     \
+          (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                                         \
+  } while (0)
+#else
+#define TRACE_MARK(slot) do {} while (0)
+#define TRACE_HWID(slot) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int NT_BM = 128;
@@ -300,9 +324,25 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   };
 
   const int nk = (a.K + NT_BK - 1) / NT_BK;
+#ifdef JTVAE_GEMM_LAB_PRIO  // experiment: distinct static issue priorities for the waves sharing a SIMD
+  {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;  // HW_ID.wave_id
+#if JTVAE_GEMM_LAB_PRIO == 2
+    const unsigned pr = blockIdx.x & 3u;
+#else
+    const unsigned pr = slot;
+#endif
+    if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
+#endif
+  TRACE_HWID(0);
+  TRACE_MARK(1);
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
+  TRACE_MARK(2);
 
   // operand fragment addresses: lane l supplies row (l & 31); its half (l >> 5) picks which
   // four of the eight k values of a step group it feeds.  The same k permutation is used
@@ -331,14 +371,22 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
       for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
     }
+    TRACE_MARK(3 + 4 * kt);  // MFMAs of this tile issued
     __syncthreads();
+    TRACE_MARK(4 + 4 * kt);  // every wave of the block is past its MFMAs
     if (more) {
       store_tiles((kt + 1) * NT_BK);
+      TRACE_MARK(5 + 4 * kt);  // next tile arrived and written to LDS
       __syncthreads();
     }
+    TRACE_MARK(6 + 4 * kt);  // next tile staged by every wave
   }
 
   // epilogue: accumulator register r of lane l is C[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31]
+#ifdef JTVAE_GEMM_LAB_NO_EPILOGUE  // timing experiments only: keep the accumulators alive, write nothing
+  for (int t = 0; t < NT_NT; ++t) asm volatile("" ::"v"(acc[t]));
+  if (a.M >= 0) return;
+#endif
   if (EVEC) {
     // Turn each 32 x 32 accumulator through the wave's own LDS patch (the operand tiles are dead
     // after the loop's last barrier) so that a lane ends up with float4s along the rows: the
@@ -363,6 +411,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] = ld4(&stage[((lane >> 3) + 8 * j) * NT_EPI_LD + 4 * (lane & 7)]);
       __builtin_amdgcn_wave_barrier();
+      TRACE_MARK(70 + 2 * t);  // accumulator turned through LDS
       // two rows at a time: their operand reads overlap, and the register footprint stays under
       // the 128-VGPR budget of four resident blocks
 #pragma unroll
@@ -372,6 +421,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
         const float4 v2[2] = {v[j], v[j + 1]};
         epi_store_vec<MODE, 2>(a, R2, ok2, n0 + 32 * t + 4 * (lane & 7), v2);
       }
+      TRACE_MARK(71 + 2 * t);  // its results issued to memory
     }
   } else {
     const int col_in_tile = lane & 31;
@@ -384,6 +434,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
       for (int t = 0; t < NT_NT; ++t) epi_store<MODE>(a, R, n0 + 32 * t + col_in_tile, acc[t][r]);
     }
   }
+  TRACE_MARK(80);  // results written
 }
 
 // ---------------------------------------------------------------------------------------
