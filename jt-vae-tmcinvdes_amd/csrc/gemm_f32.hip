@@ -324,19 +324,6 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   };
 
   const int nk = (a.K + NT_BK - 1) / NT_BK;
-#ifdef JTVAE_GEMM_LAB_PRIO  // experiment: distinct static issue priorities for the waves sharing a SIMD
-  {
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u;  // HW_ID.wave_id
-#if JTVAE_GEMM_LAB_PRIO == 2
-    const unsigned pr = blockIdx.x & 3u;
-#else
-    const unsigned pr = slot;
-#endif
-    if (pr == 1) __builtin_amdgcn_s_setprio(1);
-    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
-    else if (pr == 3) __builtin_amdgcn_s_setprio(3);
-  }
-#endif
   TRACE_HWID(0);
   TRACE_MARK(1);
   load_tiles(0);
@@ -383,10 +370,6 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   }
 
   // epilogue: accumulator register r of lane l is C[row (r&3) + 8(r>>2) + 4(l>>5)][col l&31]
-#ifdef JTVAE_GEMM_LAB_NO_EPILOGUE  // timing experiments only: keep the accumulators alive, write nothing
-  for (int t = 0; t < NT_NT; ++t) asm volatile("" ::"v"(acc[t]));
-  if (a.M >= 0) return;
-#endif
   if (EVEC) {
     // Turn each 32 x 32 accumulator through the wave's own LDS patch (the operand tiles are dead
     // after the loop's last barrier) so that a lane ends up with float4s along the rows: the
