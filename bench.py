@@ -30,7 +30,8 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense, spec
 HBM_KERNELS = ("gru_gate_gather", "gru_bwd_gather", "gru_bwd_pointwise", "csr_gather_sum", "slab_sum",
-               "segment_mean", "segment_mean_bwd", "gru_iter0", "copy_rows", "colsum", "transpose")
+               "segment_mean", "segment_mean_bwd", "gru_iter0", "copy_rows", "colsum", "transpose", "pack_batch",
+               "select_slab_rows", "row_dot")
 MFMA_KERNELS = ("gemm_nt", "gemm_tn")
 
 

@@ -51,7 +51,7 @@ extern "C" {
 
 /* epilogue modes for jtvae_gemm_nt */
 #define JTVAE_EPI_PLAIN 0     /* C = act(acc + bias + add)                                   */
-#define JTVAE_EPI_GRU_BLEND 1 /* p = tanh(acc+add); C = p; out2 = (1-z)*s + z*p (row 0 -> 0) */
+#define JTVAE_EPI_GRU_BLEND 1 /* p = tanh(acc+add); C = p; out2 = (1-z)*s + z*p, 0 on zero_row */
 #define JTVAE_EPI_MUL_ACC 2   /* C = acc (+add); out2 += C * aux0                            */
 
 typedef struct jtvae_epilogue {
@@ -95,17 +95,36 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
  * atomics).  x_rows / y_rows (int32 [M], or NULL = identity) pick the row of X and of Y for every
  * reduction index: the tree GRU contracts compactly stored gradient rows against saved state rows
  * scattered over per-iteration slabs.  Replaces autograd's addmm backward for every Linear on the
- * path.  workspace: at least jtvae_gemm_tn_workspace_bytes(M,N,K) bytes of device memory. */
+ * path.  dbias ([N], or NULL): also dbias[n] (+)= sum_m X[xr(m), n], the gradient of the Linear's
+ * bias, from a virtual column of ones appended to Y (it rides in the padding of the last column
+ * tile, so it costs no extra pass over X).
+ * workspace: at least jtvae_gemm_tn_workspace_bytes(M,N,K) bytes of device memory. */
 size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
-                  const int32_t* y_rows, float* dW, int32_t lddw, int32_t M, int32_t N, int32_t K,
-                  int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                  const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N,
+                  int32_t K, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out[c] (+)= sum_m X[m,c] for c < N (bias gradients), fixed summation order.
  * workspace: jtvae_colsum_workspace_bytes(M,N). */
 size_t jtvae_colsum_workspace_bytes(int32_t M, int32_t N);
 int jtvae_colsum(const float* X, int32_t ldx, float* out, int32_t M, int32_t N, int32_t accumulate,
                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* Up to JTVAE_PACK_MAX copies / transposes in one launch: the weights of a module laid out as
+ * 16-byte-row GEMM operands.  transpose == 0: dst[r, c] = src[r, c]; transpose != 0:
+ * dst[c, r] = src[r, c]; r < rows, c < cols; the remaining columns of every destination row up
+ * to ld_dst are written as zero.  `items` is a host array, read during the call.  Replaces the
+ * implicit layout handling of nn.Linear (weight slices of torch.cat inputs, fast_jtnn/mpn.py:98,
+ * jtnn_enc.py:114,123) and the weight transposes of autograd's addmm backward. */
+#define JTVAE_PACK_MAX 16
+typedef struct jtvae_pack_item {
+  const float* src;
+  float* dst;
+  int32_t ld_src, ld_dst;
+  int32_t rows, cols; /* extent of the source block */
+  int32_t transpose;
+} jtvae_pack_item_t;
+int jtvae_pack_batch(const jtvae_pack_item_t* items, int32_t n_items, void* stream);
 
 /* dst[c,r] = src[r,c] for r < rows, c < cols (weight transposes for the dgrad GEMMs). */
 int jtvae_transpose(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows,

@@ -527,7 +527,20 @@ struct TnArgs {
   int ldx, ldy, ldp;
   int M, N, K;
   int tiles_n, tiles_k, rows_per_split;
+  int ones_col;  // 1: Y carries a virtual column K of ones, so P[:, K] = column sums of X (bias gradient)
 };
+
+// mask4 for the Y tile: the virtual ones column sits at k == K
+__device__ __forceinline__ float4 mask4_ones(float4 v, bool row_ok, int k, int K, int ones_col) {
+  v = mask4(v, row_ok, k, K);
+  if (ones_col && row_ok) {
+    if (k + 0 == K) v.x = 1.f;
+    if (k + 1 == K) v.y = 1.f;
+    if (k + 2 == K) v.z = 1.f;
+    if (k + 3 == K) v.w = 1.f;
+  }
+  return v;
+}
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
@@ -581,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
     for (int i = 0; i < 3; ++i) {
       int idx = tid + 256 * i;
       *reinterpret_cast<float4*>(&Ys[(idx / 24) * TN_BKK + 4 * (idx % 24)]) =
-          mask4(ry[i], mb + idx / 24 < m_end, k0 + 4 * (idx % 24), a.K);
+          mask4_ones(ry[i], mb + idx / 24 < m_end, k0 + 4 * (idx % 24), a.K, a.ones_col);
     }
   };
 
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int k = k0 + 32 * t + (lane & 31);
-    if (k >= a.K) continue;
+    if (k >= a.K + a.ones_col) continue;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = n0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -630,17 +643,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   }
 }
 
+// sums the slab partials in slab order; column K (present when dbias is given) goes to dbias
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ P, int splits, int N, int K,
                                                           int ldp, float* __restrict__ dW, int lddw,
-                                                          int accumulate) {
+                                                          float* __restrict__ dbias, int accumulate) {
+  const int Kx = K + (dbias ? 1 : 0);
   long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long)N * K) return;
-  int n = (int)(gid / K), k = (int)(gid - (long)n * K);
+  if (gid >= (long)N * Kx) return;
+  int n = (int)(gid / Kx), k = (int)(gid - (long)n * Kx);
   const float* p = P + (size_t)n * ldp + k;
   const size_t stride = (size_t)N * ldp;
   float acc = 0.f;
   for (int s = 0; s < splits; ++s) acc += p[s * stride];
-  float* o = dW + (size_t)n * lddw + k;
+  float* o = k < K ? dW + (size_t)n * lddw + k : dbias + n;
   *o = accumulate ? *o + acc : acc;
 }
 
@@ -681,10 +696,10 @@ inline int launch_status() {
 struct TnPlan {
   int tiles_n, tiles_k, splits, rows_per_split, ldp;
 };
-inline TnPlan tn_plan(int M, int N, int K) {
+inline TnPlan tn_plan(int M, int N, int K, int ones_col) {
   TnPlan p;
   p.tiles_n = (N + TN_BN - 1) / TN_BN;
-  p.tiles_k = (K + TN_BKK - 1) / TN_BKK;
+  p.tiles_k = (K + ones_col + TN_BKK - 1) / TN_BKK;
   int tiles = p.tiles_n * p.tiles_k;
   int want = (M + 255) / 256;               // at least 256 rows per slab
   int cap = (1024 + tiles - 1) / tiles;     // about four blocks per CU in total
@@ -695,7 +710,7 @@ inline TnPlan tn_plan(int M, int N, int K) {
   if (rows < TN_BM) rows = TN_BM;
   p.rows_per_split = rows;
   p.splits = M > 0 ? (M + rows - 1) / rows : 1;
-  p.ldp = (K + 3) & ~3;
+  p.ldp = (K + 1 + 3) & ~3;  // room for the ones column either way
   return p;
 }
 
@@ -789,16 +804,19 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
 
 size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   if (M < 0 || N <= 0 || K <= 0) return 0;
-  TnPlan p = tn_plan(M, N, K);
-  return (size_t)p.splits * N * p.ldp * sizeof(float);
+  // enough for both forms of the call (with and without the bias column)
+  TnPlan p0 = tn_plan(M, N, K, 0), p1 = tn_plan(M, N, K, 1);
+  size_t s = p0.splits > p1.splits ? p0.splits : p1.splits;
+  return s * N * p0.ldp * sizeof(float);
 }
 
 int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
-                  const int32_t* y_rows, float* dW, int32_t lddw, int32_t M, int32_t N, int32_t K,
+                  const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N, int32_t K,
                   int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   if (M < 0 || N <= 0 || K <= 0 || ldx < N || ldy < K || lddw < K) return JTVAE_E_SHAPE;
   if (!X || !Y || !dW || !workspace) return JTVAE_E_NULL;
-  TnPlan p = tn_plan(M, N, K);
+  const int ones_col = dbias ? 1 : 0;
+  TnPlan p = tn_plan(M, N, K, ones_col);
   if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float)) return JTVAE_E_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(workspace) & 15) return JTVAE_E_ALIGN;
   TnArgs a;
@@ -806,15 +824,16 @@ int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const floa
   a.ldx = ldx; a.ldy = ldy; a.ldp = p.ldp;
   a.M = M; a.N = N; a.K = K;
   a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.rows_per_split = p.rows_per_split;
+  a.ones_col = ones_col;
   hipStream_t s = (hipStream_t)stream;
   int blocks = p.tiles_n * p.tiles_k * p.splits;
   if (aligned16(X, ldx) && aligned16(Y, ldy))
     hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
-  long total = (long)N * K;
+  long total = (long)N * (K + ones_col);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.P, p.splits, N,
-                     K, p.ldp, dW, lddw, accumulate);
+                     K, p.ldp, dW, lddw, dbias, accumulate);
   return launch_status();
 }
 

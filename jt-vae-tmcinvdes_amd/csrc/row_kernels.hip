@@ -152,6 +152,45 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   }
 }
 
+// Several small matrices (the Linear weights of one module) packed or transposed into 16-byte-row
+// buffers by one launch: block b serves one 32 x 32 tile of one destination.  Padding columns of
+// every destination row are written as zero.
+struct PackArgs {
+  jtvae_pack_item_t it[JTVAE_PACK_MAX];
+  int tile_end[JTVAE_PACK_MAX];  // running total of tiles after item i
+  int n;
+};
+__global__ __launch_bounds__(256) void pack_batch_kernel(PackArgs a) {
+  __shared__ float tile[32][33];
+  int i = 0;
+  while (i + 1 < a.n && (int)blockIdx.x >= a.tile_end[i]) ++i;
+  const jtvae_pack_item_t& it = a.it[i];
+  const int local = blockIdx.x - (i ? a.tile_end[i - 1] : 0);
+  const int drows = it.transpose ? it.cols : it.rows;   // destination rows
+  const int dvalid = it.transpose ? it.rows : it.cols;  // destination columns that hold data
+  const int tiles_c = (it.ld_dst + 31) / 32;
+  const int r0 = (local / tiles_c) * 32, c0 = (local % tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  if (it.transpose) {
+    // destination tile [r0.., c0..] = source tile [c0.., r0..] turned through LDS
+    for (int k = ty; k < 32; k += 8) {
+      const int sr = c0 + k, sc = r0 + tx;
+      tile[k][tx] = (sr < it.rows && sc < it.cols) ? it.src[(size_t)sr * it.ld_src + sc] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+      const int dr = r0 + k, dc = c0 + tx;
+      if (dr < drows && dc < it.ld_dst) it.dst[(size_t)dr * it.ld_dst + dc] = dc < dvalid ? tile[tx][k] : 0.f;
+    }
+  } else {
+    for (int k = ty; k < 32; k += 8) {
+      const int dr = r0 + k, dc = c0 + tx;
+      if (dr < drows && dc < it.ld_dst)
+        it.dst[(size_t)dr * it.ld_dst + dc] = dc < dvalid ? it.src[(size_t)dr * it.ld_src + dc] : 0.f;
+    }
+  }
+}
+
 // score[c] = <q[owner[c]], cand[c]>, one wave per candidate
 __global__ __launch_bounds__(JTVAE_BLOCK) void row_dot_kernel(float* __restrict__ score,
                                                               const float* __restrict__ q,
@@ -284,6 +323,27 @@ int jtvae_transpose(const float* src, int32_t ld_src, float* dst, int32_t ld_dst
   dim3 grid((cols + 31) / 32, (rows + 31) / 32);
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows,
                      cols);
+  return launch_status();
+}
+
+int jtvae_pack_batch(const jtvae_pack_item_t* items, int32_t n_items, void* stream) {
+  if (n_items < 0 || n_items > JTVAE_PACK_MAX) return JTVAE_E_SHAPE;
+  if (n_items == 0) return 0;
+  if (!items) return JTVAE_E_NULL;
+  PackArgs a;
+  int total = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const jtvae_pack_item_t& it = items[i];
+    if (it.rows <= 0 || it.cols <= 0 || it.cols > it.ld_src) return JTVAE_E_SHAPE;
+    if ((it.transpose ? it.rows : it.cols) > it.ld_dst) return JTVAE_E_SHAPE;
+    if (!it.src || !it.dst) return JTVAE_E_NULL;
+    const int drows = it.transpose ? it.cols : it.rows;
+    total += ((drows + 31) / 32) * ((it.ld_dst + 31) / 32);
+    a.it[i] = it;
+    a.tile_end[i] = total;
+  }
+  a.n = n_items;
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, a);
   return launch_status();
 }
 

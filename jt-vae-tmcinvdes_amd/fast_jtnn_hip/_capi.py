@@ -51,6 +51,19 @@ class Epilogue(C.Structure):
     ]
 
 
+class PackItem(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p),
+        ("dst", C.c_void_p),
+        ("ld_src", C.c_int32),
+        ("ld_dst", C.c_int32),
+        ("rows", C.c_int32),
+        ("cols", C.c_int32),
+        ("transpose", C.c_int32),
+    ]
+
+
+PACK_MAX = 16
 _i32, _vp, _sz = C.c_int32, C.c_void_p, C.c_size_t
 
 # name -> (restype, argtypes); must list every function of include/jtvae_hip.h
@@ -59,9 +72,11 @@ SIGNATURES = {
     "jtvae_error_string": (C.c_char_p, [C.c_int]),
     "jtvae_gemm_nt": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
     "jtvae_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "jtvae_gemm_tn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "jtvae_gemm_tn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _sz,
+                                _vp]),
     "jtvae_colsum_workspace_bytes": (_sz, [_i32, _i32]),
     "jtvae_colsum": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "jtvae_pack_batch": (C.c_int, [C.POINTER(PackItem), _i32, _vp]),
     "jtvae_transpose": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_csr_gather_sum": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
@@ -207,10 +222,11 @@ def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0
          tag="M=%d N=%d K=%d mode=%d" % (M, N, K, mode))
 
 
-def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device, x_rows=None, y_rows=None):
+def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device, x_rows=None, y_rows=None, dbias=None):
+    """dW (+)= X^T Y over the M rows (or row pairs); dbias (+)= column sums of the same X rows."""
     nbytes = lib.jtvae_gemm_tn_workspace_bytes(M, N, K)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-    _run("gemm_tn", lib.jtvae_gemm_tn, (X, ldx, x_rows, Y, ldy, y_rows, dW, lddw, M, N, K, int(accumulate),
+    _run("gemm_tn", lib.jtvae_gemm_tn, (X, ldx, x_rows, Y, ldy, y_rows, dW, lddw, dbias, M, N, K, int(accumulate),
                                         ws.data_ptr(), nbytes, stream_ptr()),
          nbytes=4 * (M * N + M * K + N * K), flops=2 * M * N * K, tag="M=%d N=%d K=%d" % (M, N, K))
 
@@ -220,6 +236,16 @@ def colsum(X, ldx, out, M, N, accumulate, device):
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
     _run("colsum", lib.jtvae_colsum, (X, ldx, out, M, N, int(accumulate), ws.data_ptr(), nbytes, stream_ptr()),
          nbytes=4 * (M * N + N))
+
+
+def pack_batch(items):
+    """items: list of (src_ptr, ld_src, dst_ptr, ld_dst, rows, cols, transpose); one launch per 16."""
+    for i in range(0, len(items), PACK_MAX):
+        chunk = items[i:i + PACK_MAX]
+        arr = (PackItem * len(chunk))(*[PackItem(src=it[0], ld_src=it[1], dst=it[2], ld_dst=it[3], rows=it[4],
+                                                cols=it[5], transpose=it[6]) for it in chunk])
+        _run("pack_batch", lib.jtvae_pack_batch, (arr, len(chunk), stream_ptr()),
+             nbytes=sum(8 * it[4] * it[5] for it in chunk))
 
 
 def transpose(src, ld_src, dst, ld_dst, nrows, ncols):

@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from . import _capi as K
 from . import graphprep
-from .mpn import _pack_weight, _pack_weight_t, as_row_buffer, dense_view
+from .mpn import as_row_buffer, dense_view, pack_weights
 
 
 SCHEDULE = "level"  # "level": update only messages that can still change; "dense": the reference's schedule
@@ -164,10 +164,9 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         Eu = K.rows(NW, ld, dev)
         K.csr_gather_sum(Eu.data_ptr(), E_p.data_ptr(), E.shape[0], None, P.word_csr.rowptr.data_ptr(),
                          P.word_csr.col.data_ptr(), NW, H, ld, nnz=NW)
-        Wzx, Wzh = _pack_weight(Wz, 0, H), _pack_weight(Wz, H, H)
-        Whx, Whh = _pack_weight(Wh, 0, H), _pack_weight(Wh, H, H)
-        Wox, Woh = _pack_weight(Wout, 0, H), _pack_weight(Wout, H, H)
-        Wr_p, Ur_p = _pack_weight(Wr, 0, H), _pack_weight(Ur_w, 0, H)
+        Wzx, Wzh, Whx, Whh, Wox, Woh, Wr_p, Ur_p = pack_weights(
+            [(Wz, 0, H, False), (Wz, H, H, False), (Wh, 0, H, False), (Wh, H, H, False), (Wout, 0, H, False),
+             (Wout, H, H, False), (Wr, 0, H, False), (Ur_w, 0, H, False)])
         Pz, Pr, Ph, Po = (K.rows(NW, ld, dev) for _ in range(4))
         K.gemm_nt(Eu.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NW, H, H, bias=bz.detach().data_ptr())
         K.gemm_nt(Eu.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NW, H, H)
@@ -209,7 +208,10 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         dUr = torch.empty((H, H), dtype=torch.float32, device=dev)
         dbout, dbz, dbu, dbh = (torch.empty((H,), dtype=torch.float32, device=dev) for _ in range(4))
 
-        WohT = _pack_weight_t(Wout, H, H)
+        # transposed weights of every dgrad GEMM of this backward pass
+        WohT, WzhT, WhhT, UrT, WzxT, WhxT, WoxT, WrT = pack_weights(
+            [(Wout, H, H, True), (Wz, H, H, True), (Wh, H, H, True), (Ur_w, 0, H, True), (Wz, 0, H, True),
+             (Wh, 0, H, True), (Wout, 0, H, True), (Wr, 0, H, True)])
         # root stage: relu mask, W_out[:, H:] gradient, back to the messages that feed a root
         dpre_root = K.rows(B, ld, dev)
         if dtv is None:
@@ -228,7 +230,6 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         K.csr_gather_sum(dh.data_ptr(), dnsum.data_ptr(), B, None, P.rcsr_t.rowptr.data_ptr(),
                          P.rcsr_t.col.data_ptr(), NM, H, ld, accumulate=dmess is not None, nnz=P.rcsr_t.nnz)
 
-        WzhT, WhhT, UrT = _pack_weight_t(Wz, H, H), _pack_weight_t(Wh, H, H), _pack_weight_t(Ur_w, 0, H)
         if T >= 1:
             dz, dp, du, a_r = _TreeGRU.backward(dh, sched, bs, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT,
                                                 WhhT, UrT)
@@ -259,14 +260,13 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         else:
             dPz, dPh, dPr = (K.rows(NW, ld, dev, zero=True) for _ in range(3))
         for dPt, dW, db in ((dPz, dWz, dbz), (dPh, dWh, dbh), (dPo, dWout, dbout)):
-            K.gemm_tn(dPt.data_ptr(), ld, Eu.data_ptr(), ld, dW.data_ptr(), 2 * H, NW, H, H, False, dev)
-            K.colsum(dPt.data_ptr(), ld, db.data_ptr(), NW, H, False, dev)
+            K.gemm_tn(dPt.data_ptr(), ld, Eu.data_ptr(), ld, dW.data_ptr(), 2 * H, NW, H, H, False, dev,
+                      dbias=db.data_ptr())
         K.gemm_tn(dPr.data_ptr(), ld, Eu.data_ptr(), ld, dWr.data_ptr(), H, NW, H, H, False, dev)
         # embedding gradient: dEu = sum_tables dP W[:, :H], scattered to the rows of the words used
         dEu = K.rows(NW, ld, dev)
         first = True
-        for dPt, W in ((dPz, Wz), (dPh, Wh), (dPo, Wout), (dPr, Wr)):
-            WT = _pack_weight_t(W, 0, H)
+        for dPt, WT in ((dPz, WzxT), (dPh, WhxT), (dPo, WoxT), (dPr, WrT)):
             K.gemm_nt(dPt.data_ptr(), ld, WT.data_ptr(), ld, dEu.data_ptr(), ld, NW, H, H,
                       add=None if first else dEu.data_ptr(), ld_add=ld)
             first = False
@@ -318,9 +318,9 @@ class GraphGRU(nn.Module):
         with torch.cuda.device(dev), torch.no_grad():
             x_p = as_row_buffer(x.to(dev), H, ld)
             Wz, Wh = self.W_z.weight, self.W_h.weight
-            Wzx, Wzh = _pack_weight(Wz, 0, H), _pack_weight(Wz, H, H)
-            Whx, Whh = _pack_weight(Wh, 0, H), _pack_weight(Wh, H, H)
-            Wr_p, Ur_p = _pack_weight(self.W_r.weight, 0, H), _pack_weight(self.U_r.weight, 0, H)
+            Wzx, Wzh, Whx, Whh, Wr_p, Ur_p = pack_weights(
+                [(Wz, 0, H, False), (Wz, H, H, False), (Wh, 0, H, False), (Wh, H, H, False),
+                 (self.W_r.weight, 0, H, False), (self.U_r.weight, 0, H, False)])
             Pz, Pr, Ph = (K.rows(NM, ld, dev) for _ in range(3))
             K.gemm_nt(x_p.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NM, H, H,
                       bias=self.W_z.bias.data_ptr())

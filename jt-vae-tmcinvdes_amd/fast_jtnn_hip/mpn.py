@@ -33,28 +33,43 @@ BOND_FDIM = MPN_BOND_FDIM  # 12, fast_jtnn/mpn.py:36
 MAX_NB = MPN_MAX_NB  # 6,  fast_jtnn/mpn.py:37
 
 
+def pack_weights(specs):
+    """GEMM operands of Linear weights, all produced by one launch.
+
+    ``specs``: list of ``(weight, col0, ncols, transposed)``.  Plain: columns ``[col0, col0+ncols)`` of the
+    weight as ``[out, round4(ncols)]``; transposed: the same block turned, ``[ncols, round4(out)]`` (the
+    operand of the dgrad GEMM).  Padding columns are zero.  Returns the buffers in order; they share one
+    allocation.
+    """
+    shapes, total = [], 0
+    for w, col0, ncols, transposed in specs:
+        out_f = w.shape[0]
+        rows, ld = (ncols, K.round_ld(out_f)) if transposed else (out_f, K.round_ld(ncols))
+        shapes.append((rows, ld, total))
+        total += rows * ld
+    dev = specs[0][0].device
+    store = torch.empty((total,), dtype=torch.float32, device=dev)
+    bufs, items, keep = [], [], []
+    for (w, col0, ncols, transposed), (rows, ld, off) in zip(specs, shapes):
+        w = w.detach()
+        if not w.is_contiguous() or w.dtype != torch.float32:
+            w = w.contiguous().float()
+        keep.append(w)
+        buf = store[off:off + rows * ld].view(rows, ld)
+        bufs.append(buf)
+        items.append((K.ptr(w, col0), w.shape[1], buf.data_ptr(), ld, w.shape[0], ncols, 1 if transposed else 0))
+    K.pack_batch(items)
+    return bufs
+
+
 def _pack_weight(w: torch.Tensor, col0: int, ncols: int) -> torch.Tensor:
     """Columns [col0, col0+ncols) of a Linear weight as a 16-byte-row buffer [out, round4(ncols)]."""
-    w = w.detach()
-    if not w.is_contiguous():
-        w = w.contiguous()
-    out_f, in_f = w.shape
-    ld = K.round_ld(ncols)
-    buf = torch.empty((out_f, ld), dtype=torch.float32, device=w.device)
-    K.copy_rows(K.ptr(w, col0), in_f, buf.data_ptr(), ld, out_f, ncols)
-    return buf
+    return pack_weights([(w, col0, ncols, False)])[0]
 
 
 def _pack_weight_t(w: torch.Tensor, col0: int, ncols: int) -> torch.Tensor:
     """Transpose of the same column block: [ncols, round4(out)], for the dgrad GEMMs."""
-    w = w.detach()
-    if not w.is_contiguous():
-        w = w.contiguous()
-    out_f, in_f = w.shape
-    ld = K.round_ld(out_f)
-    buf = torch.zeros((ncols, ld), dtype=torch.float32, device=w.device)
-    K.transpose(K.ptr(w, col0), in_f, buf.data_ptr(), ld, out_f, ncols)
-    return buf
+    return pack_weights([(w, col0, ncols, True)])[0]
 
 
 def as_row_buffer(t: torch.Tensor, H: int, ld: int) -> torch.Tensor:
@@ -96,10 +111,8 @@ class _GraphMPNFunction(torch.autograd.Function):
         fa_dim, fb_dim = P.atom_fdim, P.bond_in_fdim
         train = any(ctx.needs_input_grad)
 
-        Wi = _pack_weight(W_i, 0, fb_dim)
-        Wh = _pack_weight(W_h, 0, H)
-        Woa = _pack_weight(W_o_w, 0, fa_dim)
-        Woh = _pack_weight(W_o_w, fa_dim, H)
+        Wi, Wh, Woa, Woh = pack_weights([(W_i, 0, fb_dim, False), (W_h, 0, H, False), (W_o_w, 0, fa_dim, False),
+                                         (W_o_w, fa_dim, H, False)])
         tree = None
         if TM:
             tree = as_row_buffer(tree_message, H, ld)
@@ -155,8 +168,7 @@ class _GraphMPNFunction(torch.autograd.Function):
         NB, NA, TM = P.n_bonds, P.n_atoms, P.n_tree
         fa_dim, fb_dim = P.atom_fdim, P.bond_in_fdim
 
-        WhT = _pack_weight_t(W_h, 0, H)
-        WohT = _pack_weight_t(W_o_w, fa_dim, H)
+        WhT, WohT = pack_weights([(W_h, 0, H, True), (W_o_w, fa_dim, H, True)])
         dW_i = torch.empty(ctx.W_i_shape, dtype=torch.float32, device=dev)
         dW_h = torch.empty((H, H), dtype=torch.float32, device=dev)
         dW_o = torch.empty(ctx.W_o_shape, dtype=torch.float32, device=dev)
@@ -171,8 +183,8 @@ class _GraphMPNFunction(torch.autograd.Function):
         w_in = ctx.W_o_shape[1]
         K.gemm_tn(dpre_o.data_ptr(), ld, P.fatoms.data_ptr(), P.fatoms.stride(0), dW_o.data_ptr(), w_in,
                   NA, H, fa_dim, False, dev)
-        K.gemm_tn(dpre_o.data_ptr(), ld, anei.data_ptr(), ld, K.ptr(dW_o, fa_dim), w_in, NA, H, H, False, dev)
-        K.colsum(dpre_o.data_ptr(), ld, db_o.data_ptr(), NA, H, False, dev)
+        K.gemm_tn(dpre_o.data_ptr(), ld, anei.data_ptr(), ld, K.ptr(dW_o, fa_dim), w_in, NA, H, H, False, dev,
+                  dbias=db_o.data_ptr())
         danei = K.rows(NA, ld, dev)
         K.gemm_nt(dpre_o.data_ptr(), ld, WohT.data_ptr(), ld, danei.data_ptr(), ld, NA, H, H)
 

@@ -132,7 +132,7 @@ def test_gemm_nt_gru_blend_and_mul_acc(K, M, pad):
 
 
 @pytest.mark.parametrize("M,N,Kd", [(1000, 450, 450), (70000, 450, 450), (5000, 450, 39), (31, 96, 51),
-                                    (4097, 450, 44)])
+                                    (4097, 450, 44), (700, 130, 96), (300, 450, 480)])
 def test_gemm_tn_and_colsum(K, M, N, Kd):
     rs = np.random.RandomState(M)
     X = rs.standard_normal((M, N)).astype(np.float32)
@@ -162,6 +162,18 @@ def test_gemm_tn_and_colsum(K, M, N, Kd):
     K.colsum(Xd.data_ptr(), ldx, out.data_ptr(), M, N, False, "cuda")
     torch.cuda.synchronize()
     assert np.abs(out.cpu().numpy() - X.astype(np.float64).sum(0)).max() / scale < 2e-5
+    # the same column sums ride along with the contraction (bias gradient), without disturbing dW
+    db = torch.full((N,), 3.0, device="cuda")
+    dW4 = torch.from_numpy(base.copy()).cuda()
+    K.gemm_tn(Xd.data_ptr(), ldx, Yd.data_ptr(), ldy, dW4.data_ptr(), Kd + 5, M, N, Kd, False, "cuda",
+              dbias=db.data_ptr())
+    torch.cuda.synchronize()
+    assert np.abs(db.cpu().numpy() - X.astype(np.float64).sum(0)).max() / scale < 2e-5
+    assert torch.equal(dW4[:, :Kd], dW2[:, :Kd]) and np.array_equal(dW4.cpu().numpy()[:, Kd:], base[:, Kd:])
+    K.gemm_tn(Xd.data_ptr(), ldx, Yd.data_ptr(), ldy, dW4.data_ptr(), Kd + 5, M, N, Kd, True, "cuda",
+              dbias=db.data_ptr())
+    torch.cuda.synchronize()
+    assert np.abs(db.cpu().numpy() - 2 * X.astype(np.float64).sum(0)).max() / scale < 4e-5
 
 
 def test_transpose_and_copy_rows(K):
@@ -175,6 +187,31 @@ def test_transpose_and_copy_rows(K):
     torch.cuda.synchronize()
     assert np.array_equal(T[:, :450].cpu().numpy(), W[:, 39:].T)
     assert np.array_equal(P[:, :39].cpu().numpy(), W[:, :39]) and float(P[:, 39].abs().max()) == 0.0
+
+
+def test_pack_batch(K):
+    """Several weight blocks copied / transposed into padded row buffers by one launch."""
+    rs = np.random.RandomState(2)
+    W1 = rs.standard_normal((450, 489)).astype(np.float32)
+    W2 = rs.standard_normal((450, 900)).astype(np.float32)
+    W3 = rs.standard_normal((56, 450)).astype(np.float32)
+    d1, d2, d3 = dev(W1), dev(W2), dev(W3)
+    specs = [(d1, W1, 0, 39, 0), (d1, W1, 39, 450, 0), (d1, W1, 39, 450, 1), (d2, W2, 450, 450, 1),
+             (d2, W2, 0, 450, 0), (d3, W3, 0, 450, 1), (d3, W3, 0, 450, 0)] * 3  # 21 items: two launches
+    items, outs = [], []
+    for d, W, c0, nc, tr in specs:
+        rows, ld = (nc, K.round_ld(W.shape[0])) if tr else (W.shape[0], K.round_ld(nc))
+        buf = keep(torch.full((rows, ld), 9.0, device="cuda"))
+        outs.append(buf)
+        items.append((K.ptr(d, c0), W.shape[1], buf.data_ptr(), ld, W.shape[0], nc, tr))
+    K.pack_batch(items)
+    torch.cuda.synchronize()
+    for (d, W, c0, nc, tr), buf in zip(specs, outs):
+        blk = W[:, c0:c0 + nc]
+        ref = blk.T if tr else blk
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[:, :ref.shape[1]], ref)
+        assert not got[:, ref.shape[1]:].any()
 
 
 def random_csr(rs, n_rows, n_src, max_deg):
