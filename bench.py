@@ -33,6 +33,17 @@ HBM_KERNELS = ("gru_gate_gather", "gru_bwd_gather", "gru_bwd_pointwise", "csr_ga
                "segment_mean", "segment_mean_bwd", "gru_iter0", "copy_rows", "colsum", "transpose", "pack_batch",
                "select_slab_rows", "row_dot")
 MFMA_KERNELS = ("gemm_nt", "gemm_tn")
+# HBM bytes per launch from the PMC counters cannot be collected from inside this process: they come from the
+# committed summary of two rocprofv3 --pmc passes over this same command (see the file's "source" field)
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+
+
+def pmc_traffic():
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            return {k: v["hbm_bytes_per_launch"] for k, v in json.load(f)["kernels"].items()}
+    except (OSError, ValueError, KeyError):
+        return {}
 
 
 def build_problem(seed, batch, vocab, device):
@@ -162,6 +173,7 @@ def main():
                 tf = d["flops"] / max(d["ms"], 1e-9) / 1e9
                 print("%-18s %-34s x%-3d %8.3f ms %7.1f TF" % (name, tag, d["launches"], d["ms"], tf), file=sys.stderr)
         kernels = []
+        traffic = pmc_traffic() if args.batch == 1024 else {}  # counters were taken on the default workload
         for name, d in kt.summary().items():
             sec = d["ms"] * 1e-3
             if name in MFMA_KERNELS:
@@ -171,7 +183,8 @@ def main():
             kernels.append({"kernel": name, "bound": bound, "launches": d["launches"],
                             "ms_per_step": round(d["ms"], 4), "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
                             "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                            "traffic": None})
+                            "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                            "traffic": round(traffic[name]) if name in traffic else None})
         kernels.sort(key=lambda k: -k["ms_per_step"])
         dom = kernels[0]
         out["roofline"] = {k: dom[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}

@@ -244,9 +244,9 @@ class _JTNNEncoderFunction(torch.autograd.Function):
             dWz[:, H:].zero_()
             dWh[:, H:].zero_()
         if T >= 1 and bs.n_u > 0:
+            # the row pairs visit every compact du row exactly once, so the fused column sum is U_r's bias gradient
             K.gemm_tn(du.data_ptr(), ld, st["hs"].data_ptr(), ld, dUr.data_ptr(), H, bs.n_u, H, H, False, dev,
-                      x_rows=bs.ux.data_ptr(), y_rows=bs.uy.data_ptr())
-            K.colsum(du.data_ptr(), ld, dbu.data_ptr(), bs.nJ, H, False, dev)
+                      x_rows=bs.ux.data_ptr(), y_rows=bs.uy.data_ptr(), dbias=dbu.data_ptr())
         else:
             dUr.zero_()
             dbu.zero_()
