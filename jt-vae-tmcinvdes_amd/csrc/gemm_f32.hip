@@ -20,6 +20,8 @@
 // 32x32 accumulators, which keeps the kernel near 128 VGPRs so that four blocks
 // (four waves per SIMD) are resident per CU: the matrix pipe of a SIMD then always has
 // a wave with MFMAs to issue while the others sit in a barrier or stage the next tile.
+#include <cstdlib>
+
 #include "jtvae_common.h"
 #include "../../include/jtvae_hip.h"
 
@@ -269,10 +271,14 @@ __device__ __forceinline__ void epi_store_vec(const NtArgs& a, const EpiRow (&R)
 constexpr int NT_EPI_LD = 40;  // LDS row stride of a wave's 32 x 32 staging tile: the two half-waves
                                // (rows r and r + 4) land in disjoint bank halves
 
-template <bool VEC, int MODE, bool EVEC>
+// NACC = 32-column accumulators per wave: 3 (block tile 128 x 96) for launches that fill the chip, 1
+// (128 x 32) for mid-size launches, where three times as many, shorter-lived blocks cut the latency
+// chain of a block that has a CU to itself.
+template <bool VEC, int MODE, bool EVEC, int NACC>
 __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[(NT_BM + NT_BN) * NT_LDS];
-  static_assert(4 * 32 * NT_EPI_LD <= (NT_BM + NT_BN) * NT_LDS, "epilogue staging must fit the operand tiles");
+  constexpr int BN = 32 * NACC;
+  __shared__ __attribute__((aligned(16))) float smem[(NT_BM + BN) * NT_LDS];
+  static_assert(4 * 32 * NT_EPI_LD <= (NT_BM + BN) * NT_LDS, "epilogue staging must fit the operand tiles");
   float* As = smem;
   float* Bs = smem + NT_BM * NT_LDS;
 
@@ -281,22 +287,22 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   const int wave = tid >> 6;
   const int tile = xcd_remap(blockIdx.x, a.n_blocks);
   const int m0 = (tile / a.n_tiles_n) * NT_BM;
-  const int n0 = (tile % a.n_tiles_n) * NT_BN;
+  const int n0 = (tile % a.n_tiles_n) * BN;
   const jtvae_epilogue_t& e = a.e;
 
-  f32x16 acc[NT_NT];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < NT_NT; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const int srow = tid >> 3;  // staging: 8 threads (8 x float4 = 32 floats) per tile row
   const int sc4 = tid & 7;
-  float4 ra[NT_BM / 32], rb[NT_BN / 32];
+  float4 ra[NT_BM / 32], rb[NACC];
 
   // row base pointers of the staged rows do not change along K: resolve row lists once
   const float* a_row[NT_BM / 32];
-  const float* b_row[NT_BN / 32];
+  const float* b_row[NACC];
 #pragma unroll
   for (int i = 0; i < NT_BM / 32; ++i) {
     int m = min(m0 + srow + 32 * i, a.M - 1);
@@ -304,13 +310,13 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
     a_row[i] = a.A + (size_t)m * a.lda;
   }
 #pragma unroll
-  for (int i = 0; i < NT_BN / 32; ++i) b_row[i] = a.W + (size_t)min(n0 + srow + 32 * i, a.N - 1) * a.ldw;
+  for (int i = 0; i < NACC; ++i) b_row[i] = a.W + (size_t)min(n0 + srow + 32 * i, a.N - 1) * a.ldw;
 
   auto load_tiles = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NT_BM / 32; ++i) ra[i] = load4_raw<VEC>(a_row[i], k0 + 4 * sc4, a.K);
 #pragma unroll
-    for (int i = 0; i < NT_BN / 32; ++i) rb[i] = load4_raw<VEC>(b_row[i], k0 + 4 * sc4, a.K);
+    for (int i = 0; i < NACC; ++i) rb[i] = load4_raw<VEC>(b_row[i], k0 + 4 * sc4, a.K);
   };
   auto store_tiles = [&](int k0) {
 #pragma unroll
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
       *reinterpret_cast<float4*>(&As[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
           mask4(ra[i], m0 + srow + 32 * i < a.M, k0 + 4 * sc4, a.K);
 #pragma unroll
-    for (int i = 0; i < NT_BN / 32; ++i)
+    for (int i = 0; i < NACC; ++i)
       *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
           mask4(rb[i], n0 + srow + 32 * i < a.N, k0 + 4 * sc4, a.K);
   };
@@ -346,17 +352,17 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
     for (int kk = 0; kk < NT_BK / 8; ++kk) {
       if (kk >= kk_end) break;
       float4 av = *reinterpret_cast<const float4*>(a_frag + 8 * kk);
-      float4 bv[NT_NT];
+      float4 bv[NACC];
 #pragma unroll
-      for (int t = 0; t < NT_NT; ++t) bv[t] = *reinterpret_cast<const float4*>(b_frag + t * 32 * NT_LDS + 8 * kk);
+      for (int t = 0; t < NACC; ++t) bv[t] = *reinterpret_cast<const float4*>(b_frag + t * 32 * NT_LDS + 8 * kk);
 #pragma unroll
-      for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
+      for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
+      for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
+      for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < NT_NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
+      for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[t].w, acc[t], 0, 0, 0);
     }
     TRACE_MARK(3 + 4 * kt);  // MFMAs of this tile issued
     __syncthreads();
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
       R[j] = epi_row<MODE>(a, ok[j] ? i : 0);
     }
 #pragma unroll
-    for (int t = 0; t < NT_NT; ++t) {
+    for (int t = 0; t < NACC; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * NT_EPI_LD + (lane & 31)] = acc[t][r];
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
       if (i >= a.M) continue;
       const EpiRow R = epi_row<MODE>(a, i);
 #pragma unroll
-      for (int t = 0; t < NT_NT; ++t) epi_store<MODE>(a, R, n0 + 32 * t + col_in_tile, acc[t][r]);
+      for (int t = 0; t < NACC; ++t) epi_store<MODE>(a, R, n0 + 32 * t + col_in_tile, acc[t][r]);
     }
   }
   TRACE_MARK(80);  // results written
@@ -731,18 +737,29 @@ void launch_nt_small(NtArgs a, hipStream_t s) {
   }
 }
 
-template <bool VEC, bool EVEC>
-void launch_nt(const NtArgs& a, hipStream_t s) {
+template <bool VEC, bool EVEC, int NACC>
+void launch_nt(NtArgs a, hipStream_t s) {
+  a.n_tiles_n = (a.N + 32 * NACC - 1) / (32 * NACC);
+  a.n_blocks = ((a.M + NT_BM - 1) / NT_BM) * a.n_tiles_n;
   switch (a.e.mode) {
     case JTVAE_EPI_GRU_BLEND:
-      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_GRU_BLEND, EVEC>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_GRU_BLEND, EVEC, NACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
       break;
     case JTVAE_EPI_MUL_ACC:
-      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_MUL_ACC, EVEC>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_MUL_ACC, EVEC, NACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
       break;
     default:
-      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_PLAIN, EVEC>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_PLAIN, EVEC, NACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
   }
+}
+
+// Row count up to which the narrow (128 x 32) tiling is used; JTVAE_NT_NARROW_MAX_M overrides it for tuning.
+int narrow_max_rows() {
+  static const int v = [] {
+    const char* e = getenv("JTVAE_NT_NARROW_MAX_M");
+    return e ? atoi(e) : 10000;
+  }();
+  return v;
 }
 
 // every row buffer the epilogue touches can be accessed as float4 at columns n % 4 == 0
@@ -785,20 +802,19 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
   if (e.mode == JTVAE_EPI_GRU_BLEND && (!e.aux0 || !e.aux1 || !e.out2 || e.ld_aux < N)) return JTVAE_E_NULL;
   if (e.mode == JTVAE_EPI_MUL_ACC && (!e.aux0 || !e.out2 || e.ld_aux < N)) return JTVAE_E_NULL;
   if (e.aux_sf && e.aux_t < 0) return JTVAE_E_SHAPE;
-  int tiles_m = (M + NT_BM - 1) / NT_BM;
-  a.n_tiles_n = (N + NT_BN - 1) / NT_BN;
-  a.n_blocks = tiles_m * a.n_tiles_n;
   const bool vec = aligned16(A, lda) && aligned16(W, ldw);
   a.evec = epilogue_aligned(a) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   if (vec && M <= SM_MAX_ROWS && K <= SM_KMAX)
     launch_nt_small(a, s);
+  else if (vec && a.evec && M <= narrow_max_rows())
+    launch_nt<true, true, 1>(a, s);
   else if (vec && a.evec)
-    launch_nt<true, true>(a, s);
+    launch_nt<true, true, 3>(a, s);
   else if (vec)
-    launch_nt<true, false>(a, s);
+    launch_nt<true, false, 3>(a, s);
   else
-    launch_nt<false, false>(a, s);
+    launch_nt<false, false, 3>(a, s);
   return launch_status();
 }
 

@@ -46,7 +46,7 @@ def dev(x):
 
 
 @pytest.mark.parametrize("M,N,Kd", [(1, 450, 450), (129, 450, 450), (1000, 450, 450), (257, 96, 96),
-                                    (300, 450, 51), (64, 450, 39), (515, 33, 7)])
+                                    (300, 450, 51), (64, 450, 39), (515, 33, 7), (10111, 450, 450), (12000, 56, 450)])
 def test_gemm_nt_plain(K, M, N, Kd):
     rs = np.random.RandomState(M + N + Kd)
     A = rs.standard_normal((M, Kd)).astype(np.float32)
@@ -75,7 +75,7 @@ def test_gemm_nt_plain(K, M, N, Kd):
             assert float(C[:, N:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,pad", [(333, 0), (777, 0), (777, 3)])
+@pytest.mark.parametrize("M,pad", [(333, 0), (777, 0), (777, 3), (10300, 0)])
 def test_gemm_nt_table_addend_and_activations(K, M, pad):
     rs = np.random.RandomState(5)
     N, Kd, V = 450, 450, 17
@@ -94,7 +94,7 @@ def test_gemm_nt_table_addend_and_activations(K, M, pad):
         assert rel_err(C[:, :N].cpu().numpy(), fn(pre)) < 3e-6
 
 
-@pytest.mark.parametrize("M,pad", [(200, 0), (900, 0), (900, 1)])
+@pytest.mark.parametrize("M,pad", [(200, 0), (900, 0), (900, 1), (10300, 0)])
 def test_gemm_nt_gru_blend_and_mul_acc(K, M, pad):
     rs = np.random.RandomState(6)
     N = 450
