@@ -164,6 +164,8 @@ def main():
                    "parallelism": "dp%d" % world, "grad_bucket_bytes": bucket.nbytes(), **stats},
     }
 
+    if not args.no_kernel_timing and rank != 0:
+        step()  # keeps the collective of rank 0's instrumented step matched
     if rank == 0 and not args.no_kernel_timing:
         # one extra, untimed step with every C-ABI launch bracketed by HIP events on its stream
         with K.KernelTimer() as kt:
