@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="print a per-shape GEMM table to stderr")
+    ap.add_argument("--backend", default="nccl", help="collective backend; gloo lets several ranks rehearse the "
+                                                      "N > 1 path on one GPU")
     args = ap.parse_args()
 
     from fast_jtnn_hip import _capi as K
@@ -119,9 +121,12 @@ def main():
             raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU path in the product")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    parallel.init_process_group("nccl")
+    dev_index = local_rank % torch.cuda.device_count()  # identity on a node with one GPU per rank
+    if args.backend == "nccl" and dev_index != local_rank:
+        raise SystemExit("RCCL needs one GPU per rank: %d ranks, %d GPUs" % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    parallel.init_process_group(args.backend, device_index=dev_index)
 
     model, jt, mp, stats = build_problem(seed=1234 + rank, batch=args.batch, vocab=args.vocab, device=device)
     bucket = parallel.FlatGradBucket([p for p in model.parameters() if p.requires_grad])
@@ -158,7 +163,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic batch of %d molecular graphs per GPU (~40 atoms, <=6 neighbours): "
                                "MPN depthG=3 + JTNNEncoder/GraphGRU depthT=20, hidden 450, latent 56, "
-                               "forward + backward%s" % (args.batch, " + flat-bucket RCCL gradient all-reduce"
+                               "forward + backward%s" % (args.batch, " + flat-bucket %s gradient all-reduce" %
+                                                         ("RCCL" if args.backend == "nccl" else args.backend)
                                                          if world > 1 else ""),
                    "molecules_per_gpu": args.batch, "global_batch": args.batch * world, "vocab": args.vocab,
                    "parallelism": "dp%d" % world, "grad_bucket_bytes": bucket.nbytes(), **stats},

@@ -28,7 +28,7 @@ def dist_env() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend: str = None) -> Tuple[int, int, int]:
+def init_process_group(backend: str = None, device_index: int = None) -> Tuple[int, int, int]:
     rank, local_rank, world = dist_env()
     if world > 1 and not dist.is_initialized():
         if backend is None:
@@ -36,7 +36,7 @@ def init_process_group(backend: str = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank if device_index is None else device_index)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
