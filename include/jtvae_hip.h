@@ -229,6 +229,30 @@ int jtvae_select_slab_rows(float* out, const float* base, size_t slab_stride, co
 int jtvae_row_dot(float* score, const float* q, const int32_t* owner, const float* cand,
                   int32_t n_cand, int32_t H, int32_t ld, void* stream);
 
+/* ---- host-side index preparation (host memory in and out; no GPU work, no stream) ---------- */
+
+/* A zero-padded int64 neighbour table [rows, K] (agraph / bgraph of fast_jtnn/mpn.py:148-159 and
+ * jtmpn.py:170-181, node_graph / mess_graph of jtnn_enc.py:78-90; 0 = no neighbour) as int32 CSR
+ * without the padding slots, slot order kept.  rowptr: [rows+1]; col: capacity col_capacity
+ * (rows*K always suffices); *nnz = entries written.  Values outside [0, n_src): JTVAE_E_RANGE. */
+int jtvae_prep_padded_to_csr(const int64_t* table, int64_t rows, int32_t K, int64_t n_src,
+                             int32_t* rowptr, int32_t* col, int64_t col_capacity, int64_t* nnz);
+
+/* Transposed CSR: for every source j the rows that read it, in increasing (row, slot) order.  It
+ * turns the scatter-add of autograd's index_select backward into a gather.  trowptr: [n_src+1];
+ * tcol: [nnz]. */
+int jtvae_prep_transpose_csr(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int64_t n_src,
+                             int32_t* trowptr, int32_t* tcol);
+
+/* sf[m]: iteration from which message m of GraphGRU (jtnn_enc.py:107-128) no longer changes: 1 if
+ * it reads no message, else 1 + max over the messages it reads, capped at max(T, 1). */
+int jtvae_prep_stable_from(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t T, int32_t* sf);
+
+/* Stable grouping by key (messages by the word of their source node, for the per-word table
+ * gradients): order = item ids sorted by key, ties in input order; keyptr: [n_keys+1]. */
+int jtvae_prep_group_by_key(const int32_t* keys, int64_t n, int64_t n_keys, int32_t* keyptr,
+                            int32_t* order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,7 +59,6 @@ constexpr int NT_BM = 128;
 constexpr int NT_BN = 96;
 constexpr int NT_BK = 32;
 constexpr int NT_LDS = 36;  // floats per LDS row: 32 + 4 -> ds_read_b128 of 16 rows hits 16 distinct 16-B slots
-constexpr int NT_NT = NT_BN / 32;  // accumulators per wave
 
 // blocks that share an XCD (ids equal mod 8) get consecutive tiles, so the column
 // blocks of one row block read their A rows through one L2

@@ -64,7 +64,8 @@ class PackItem(C.Structure):
 
 
 PACK_MAX = 16
-_i32, _vp, _sz = C.c_int32, C.c_void_p, C.c_size_t
+E_NULL, E_SHAPE, E_ALIGN, E_RANGE, E_WORKSPACE = -1, -2, -3, -4, -5
+_i32, _vp, _sz, _i64 = C.c_int32, C.c_void_p, C.c_size_t, C.c_int64
 
 # name -> (restype, argtypes); must list every function of include/jtvae_hip.h
 SIGNATURES = {
@@ -78,6 +79,10 @@ SIGNATURES = {
     "jtvae_colsum": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "jtvae_pack_batch": (C.c_int, [C.POINTER(PackItem), _i32, _vp]),
     "jtvae_transpose": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_prep_padded_to_csr": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
+    "jtvae_prep_transpose_csr": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "jtvae_prep_stable_from": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "jtvae_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_csr_gather_sum": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "jtvae_slab_sum": (C.c_int, [_vp, _vp, _i32, _sz, _i32, _i32, _i32, _vp]),
@@ -320,3 +325,64 @@ def select_slab_rows(out, base, slab_stride, sel, n_rows, H, ld):
 def row_dot(score, q, owner, cand, n_cand, H, ld):
     _run("row_dot", lib.jtvae_row_dot, (score, q, owner, cand, n_cand, H, ld, stream_ptr()),
          nbytes=4 * H * 2 * n_cand + 8 * n_cand)
+
+
+# ---- host-side index preparation (numpy arrays in host memory; no GPU involved) -----------------
+
+
+def _np_ptr(a):
+    return a.__array_interface__["data"][0] if a.size else None
+
+
+def prep_padded_to_csr(table, n_src):
+    """Zero-padded int64 table [rows, K] -> (rowptr int32 [rows+1], col int32 [nnz]), slot order kept."""
+    import numpy as np
+    table = np.ascontiguousarray(table, dtype=np.int64)
+    if table.ndim != 2:
+        raise ValueError("neighbour table must be 2-D, got shape %s" % (table.shape,))
+    rows, k = table.shape
+    rowptr = np.empty(rows + 1, dtype=np.int32)
+    col = np.empty(max(rows * k, 1), dtype=np.int32)
+    nnz = C.c_int64(0)
+    rc = lib.jtvae_prep_padded_to_csr(_np_ptr(table), rows, k, int(n_src), _np_ptr(rowptr), _np_ptr(col),
+                                      col.size, C.byref(nnz))
+    if rc == E_RANGE:
+        raise IndexError("neighbour index out of range [0, %d)" % n_src)
+    check(rc, "prep_padded_to_csr")
+    return rowptr, col[:nnz.value].copy()
+
+
+def prep_transpose_csr(rowptr, col, n_src):
+    import numpy as np
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    trowptr = np.empty(int(n_src) + 1, dtype=np.int32)
+    tcol = np.empty(max(col.size, 1), dtype=np.int32)
+    rc = lib.jtvae_prep_transpose_csr(_np_ptr(rowptr), _np_ptr(col), rowptr.size - 1, int(n_src),
+                                      _np_ptr(trowptr), _np_ptr(tcol))
+    if rc == E_RANGE:
+        raise IndexError("neighbour index out of range [0, %d)" % n_src)
+    check(rc, "prep_transpose_csr")
+    return trowptr, tcol[:col.size]
+
+
+def prep_stable_from(rowptr, col, T):
+    import numpy as np
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    n = rowptr.size - 1
+    sf = np.empty(max(n, 1), dtype=np.int32)
+    check(lib.jtvae_prep_stable_from(_np_ptr(rowptr), _np_ptr(col), n, int(T), _np_ptr(sf)), "prep_stable_from")
+    return sf[:n]
+
+
+def prep_group_by_key(keys, n_keys):
+    import numpy as np
+    keys = np.ascontiguousarray(keys, dtype=np.int32)
+    keyptr = np.empty(int(n_keys) + 1, dtype=np.int32)
+    order = np.empty(max(keys.size, 1), dtype=np.int32)
+    rc = lib.jtvae_prep_group_by_key(_np_ptr(keys), keys.size, int(n_keys), _np_ptr(keyptr), _np_ptr(order))
+    if rc == E_RANGE:
+        raise IndexError("key out of range [0, %d)" % n_keys)
+    check(rc, "prep_group_by_key")
+    return keyptr, order[:keys.size]

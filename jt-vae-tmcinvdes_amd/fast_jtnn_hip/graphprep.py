@@ -12,7 +12,10 @@ The kernels want, per batch and once for all 2 / 20 iterations:
   * small derived index vectors (word id per message, molecule of each atom ...).
 
 This is index bookkeeping in the same class as tensorize itself; it runs on the
-host with numpy, once per batch, and its result is cached on the holder tuple.
+host once per batch and its result is cached on the holder tuple.  The passes over
+whole tables (CSR conversion, transposition, stable-iteration levels, grouping by
+key) are native single-pass routines of the C library; the ``*_np`` functions are
+their numpy statements, kept as the checkers of the native ones.
 """
 from __future__ import annotations
 
@@ -21,6 +24,8 @@ from typing import Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+
+from . import _capi as K
 
 
 @dataclass
@@ -37,8 +42,19 @@ def _to_np(t) -> np.ndarray:
     return np.asarray(t)
 
 
-def padded_to_csr(table: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """Rows of a zero-padded table -> (rowptr, col) keeping the slot order of the non-zeros."""
+def padded_to_csr(table: np.ndarray, n_src: int = 2 ** 31 - 1) -> Tuple[np.ndarray, np.ndarray]:
+    """Rows of a zero-padded table -> (rowptr, col) keeping the slot order of the non-zeros.
+    Entries outside [0, n_src) raise IndexError."""
+    return K.prep_padded_to_csr(table, n_src)
+
+
+def transpose_csr(rowptr: np.ndarray, col: np.ndarray, n_src: int) -> Tuple[np.ndarray, np.ndarray]:
+    """For every source row j the list of rows i that read it, ordered by (i, slot)."""
+    return K.prep_transpose_csr(rowptr, col, n_src)
+
+
+def padded_to_csr_np(table: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """numpy statement of padded_to_csr."""
     table = np.ascontiguousarray(table)
     if table.ndim != 2:
         raise ValueError("neighbour table must be 2-D, got shape %s" % (table.shape,))
@@ -50,8 +66,8 @@ def padded_to_csr(table: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     return rowptr, col.astype(np.int64)
 
 
-def transpose_csr(rowptr: np.ndarray, col: np.ndarray, n_src: int) -> Tuple[np.ndarray, np.ndarray]:
-    """For every source row j the list of rows i that read it, ordered by (i, slot)."""
+def transpose_csr_np(rowptr: np.ndarray, col: np.ndarray, n_src: int) -> Tuple[np.ndarray, np.ndarray]:
+    """numpy statement of transpose_csr."""
     n_rows = rowptr.shape[0] - 1
     counts = np.diff(rowptr)
     row_of = np.repeat(np.arange(n_rows, dtype=np.int64), counts)
@@ -69,6 +85,7 @@ def chunk_lists(rowptr: np.ndarray, chunk: int) -> Tuple[np.ndarray, np.ndarray]
     Long lists (all messages that share a word id) then sum in parallel, piece by
     piece, and the pieces of a key are added in order.
     """
+    rowptr = np.asarray(rowptr, dtype=np.int64)
     counts = np.diff(rowptr)
     n_pieces = np.maximum(1, -(-counts // chunk))  # an empty list keeps one empty piece
     key_rowptr = np.zeros(rowptr.shape[0], dtype=np.int64)
@@ -109,6 +126,19 @@ def pad_cols(x: np.ndarray, mult: int = 4) -> np.ndarray:
     fp = (f + mult - 1) // mult * mult
     out = np.zeros((n, fp), dtype=np.float32)
     out[:, :f] = x
+    return out
+
+
+def _upload_features(x: np.ndarray, device) -> torch.Tensor:
+    """[n, f] float32 -> device [n, round4(f)] with zero padding columns; the padding is added on the
+    device, so the host only hands over the array it already has."""
+    n, f = x.shape
+    fp = (f + 3) // 4 * 4
+    src = torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    if fp == f:
+        return src
+    out = torch.zeros((n, fp), dtype=torch.float32, device=device)
+    out[:, :f] = src
     return out
 
 
@@ -155,23 +185,21 @@ class GraphMPNPrep:
 
 def prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
     fatoms, fbonds, agraph, bgraph, scope = holder
-    fa, fb = _to_np(fatoms).astype(np.float32), _to_np(fbonds).astype(np.float32)
+    fa, fb = np.asarray(_to_np(fatoms), dtype=np.float32), np.asarray(_to_np(fbonds), dtype=np.float32)
     ag, bg = _to_np(agraph), _to_np(bgraph)
     na, nb = fa.shape[0], fb.shape[0]
     if ag.shape[0] != na or bg.shape[0] != nb:
         raise ValueError("agraph/bgraph row counts (%d, %d) do not match fatoms/fbonds (%d, %d)"
                          % (ag.shape[0], bg.shape[0], na, nb))
     n_src = n_tree + nb
-    b_rp, b_col = padded_to_csr(bg)
-    a_rp, a_col = padded_to_csr(ag)
-    check_range(b_col, n_src, "bgraph")
-    check_range(a_col, n_src, "agraph")
+    b_rp, b_col = padded_to_csr(bg, n_src)
+    a_rp, a_col = padded_to_csr(ag, n_src)
     bt_rp, bt_col = transpose_csr(b_rp, b_col, n_src)
     at_rp, at_col = transpose_csr(a_rp, a_col, n_src)
     seg, seg_of = scope_arrays(scope, na)
     return GraphMPNPrep(
-        fatoms=torch.from_numpy(pad_cols(fa)).to(device),
-        fbonds=torch.from_numpy(pad_cols(fb)).to(device),
+        fatoms=_upload_features(fa, device),
+        fbonds=_upload_features(fb, device),
         atom_fdim=fa.shape[1], bond_in_fdim=fb.shape[1],
         n_atoms=na, n_bonds=nb, n_tree=n_tree,
         bcsr=upload_csr(b_rp, b_col, device), bcsr_t=upload_csr(bt_rp, bt_col, device),
@@ -215,9 +243,7 @@ KEY_CHUNK = 32
 
 def _key_lists(keys: np.ndarray, n_keys: int, device):
     """Inverted index key -> members, as two-level CSR (pieces of <= KEY_CHUNK)."""
-    order = np.argsort(keys, kind="stable")
-    rp = np.zeros(n_keys + 1, dtype=np.int64)
-    np.cumsum(np.bincount(keys, minlength=n_keys), out=rp[1:])
+    rp, order = K.prep_group_by_key(keys, n_keys)
     piece_rp, key_rp = chunk_lists(rp, KEY_CHUNK)
     pieces = upload_csr(piece_rp, order.astype(np.int64), device)
     key_csr = upload_csr(key_rp, np.arange(piece_rp.shape[0] - 1, dtype=np.int64), device)
@@ -226,7 +252,7 @@ def _key_lists(keys: np.ndarray, n_keys: int, device):
 
 def prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     fnode, fmess, node_graph, mess_graph, scope = holder
-    fn, fm = _to_np(fnode).astype(np.int64), _to_np(fmess).astype(np.int64)
+    fn, fm = np.asarray(_to_np(fnode), dtype=np.int64), np.asarray(_to_np(fmess), dtype=np.int64)
     ng, mg = _to_np(node_graph), _to_np(mess_graph)
     nn_, nm = fn.shape[0], fm.shape[0]
     if ng.shape[0] != nn_ or mg.shape[0] != nm:
@@ -235,13 +261,11 @@ def prepare_tree(holder, device, vocab_size: int) -> TreePrep:
         raise ValueError("empty tree batch")
     check_range(fn, vocab_size, "fnode")
     check_range(fm, nn_, "fmess")
-    m_rp, m_col = padded_to_csr(mg)
-    check_range(m_col, nm, "mess_graph")
+    m_rp, m_col = padded_to_csr(mg, nm)
     mt_rp, mt_col = transpose_csr(m_rp, m_col, nm)
     roots = np.asarray([st for st, _ in scope], dtype=np.int64)
     check_range(roots, nn_, "scope")
-    r_rp, r_col = padded_to_csr(ng[roots])
-    check_range(r_col, nm, "node_graph")
+    r_rp, r_col = padded_to_csr(ng[roots], nm)
     rt_rp, rt_col = transpose_csr(r_rp, r_col, nm)
     nb = roots.shape[0]
 
@@ -251,7 +275,7 @@ def prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     wid_m = wid_node[fm]
     wid_root = wid_node[roots]
     w_rp = np.arange(nw + 1, dtype=np.int64)
-    wt_rp, wt_col = transpose_csr(w_rp, words, vocab_size)
+    wt_rp, wt_col = transpose_csr(w_rp.astype(np.int32), words.astype(np.int32), vocab_size)
 
     km_p, km = _key_lists(wid_m, nw, device)
     kr_p, kr = _key_lists(wid_root, nw, device)
@@ -365,7 +389,7 @@ def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False) 
     if dense or T < 1:
         sf = np.full(nm, max(T, 1), dtype=np.int64)
     else:
-        sf = _levels(m_rp, m_col, nm, max(T, 1), 1)
+        sf = K.prep_stable_from(m_rp, m_col, T).astype(np.int64)
     F, U = [], []
     total_nnz = int(m_col.shape[0])
     for t in range(T):
@@ -381,7 +405,9 @@ def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False) 
         else:
             r = np.flatnonzero((sf >= t) & (tdeg > 0))  # changed in iteration t-1 and somebody reads it
             U.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size)))
-    host = dict(m_rp=m_rp, m_col=m_col, mt_rp=mt_rp, mt_col=mt_col, sf=sf, nm=nm, deg=deg, tdeg=tdeg)
+    host = dict(m_rp=np.asarray(m_rp, dtype=np.int64), m_col=np.asarray(m_col, dtype=np.int64),
+                mt_rp=np.asarray(mt_rp, dtype=np.int64), mt_col=np.asarray(mt_col, dtype=np.int64), sf=sf, nm=nm,
+                deg=deg.astype(np.int64), tdeg=tdeg.astype(np.int64))
     return TreeSchedule(T=T, dense=dense, sf=_dev_i32(sf, device), sel_final=_dev_i32(np.minimum(sf, T), device),
                         F=F, U=U, bwd={}, _host=host)
 

@@ -1,5 +1,6 @@
 """CPU: padded neighbour tables -> CSR, transposes and key lists (host index bookkeeping)."""
 import numpy as np
+import pytest
 
 from fast_jtnn_hip import graphprep as G
 
@@ -56,3 +57,30 @@ def test_range_check():
     import pytest
     with pytest.raises(IndexError):
         G.check_range(np.array([1, 9]), 9, "x")
+
+
+def test_native_prep_matches_numpy_statements():
+    """The single-pass C routines against their numpy statements, ragged and empty inputs included."""
+    from fast_jtnn_hip import _capi as K
+    rs = np.random.RandomState(11)
+    for rows, kmax, n_src in ((0, 6, 5), (1, 1, 2), (57, 6, 57), (400, 15, 900), (33, 9, 33)):
+        t = rs.randint(0, max(n_src, 1), size=(rows, kmax)).astype(np.int64)
+        t[rs.rand(rows, kmax) < 0.5] = 0
+        rp, col = G.padded_to_csr(t, n_src)
+        rp_np, col_np = G.padded_to_csr_np(t)
+        assert rp.dtype == np.int32 and np.array_equal(rp, rp_np) and np.array_equal(col, col_np)
+        trp, tcol = G.transpose_csr(rp, col, n_src)
+        trp_np, tcol_np = G.transpose_csr_np(rp_np, col_np, n_src)
+        assert np.array_equal(trp, trp_np) and np.array_equal(tcol, tcol_np)
+        if rows == n_src:  # a message graph: rows read rows
+            for T in (0, 1, 3, 20):
+                sf = K.prep_stable_from(rp, col, T)
+                assert np.array_equal(sf, G._levels(rp_np, col_np, rows, max(T, 1), 1))
+        keys = rs.randint(0, 7, size=rows).astype(np.int64)
+        kp, order = K.prep_group_by_key(keys, 7)
+        assert np.array_equal(order, np.argsort(keys, kind="stable"))
+        assert np.array_equal(np.diff(kp), np.bincount(keys, minlength=7))
+    with pytest.raises(IndexError):
+        G.padded_to_csr(np.array([[1, 9]], dtype=np.int64), 9)
+    with pytest.raises(IndexError):
+        G.padded_to_csr(np.array([[-1, 0]], dtype=np.int64), 9)
