@@ -299,3 +299,80 @@ def test_level_schedule_is_bitwise_the_dense_schedule(with_messages):
     with torch.no_grad():
         tv_i, ms_i = make_hip_model(g, "cuda").jtnn(*g.jtenc_holder())
     assert torch.equal(tv_i, tv_l) and torch.equal(ms_i, ms_l)
+
+
+def test_level_schedule_at_batch_scale_equals_dense_to_rounding():
+    """At batch scale the row count of a launch picks the GEMM kernel (tiled or whole-K-in-LDS), whose
+    summation orders differ, so the active-row schedule and the dense one agree to fp32 rounding rather
+    than bit for bit."""
+    import fast_jtnn_hip.jtnn_enc as enc
+    from fast_jtnn_hip import synthetic, tensorize as T
+
+    class G:
+        pass
+    g = G()
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = 5, 160, 450, 56, 20, 3, 385, 0.05
+    trees = synthetic.make_batch(5, 160, vocab_size=385)
+    jt, _ = T.jtenc_tensorize(trees)
+    out = {}
+    for mode in ("dense", "level"):
+        enc.SCHEDULE = mode
+        try:
+            m = make_hip_model(g, "cuda")
+            tv, ms = m.jtnn(*jt)
+            ((tv * tv).sum() + (ms * 0.3).sin().sum()).backward()
+            out[mode] = (tv.detach().cpu().numpy(), ms.detach().cpu().numpy(),
+                         {n: p.grad.cpu().numpy() for n, p in m.jtnn.named_parameters()})
+        finally:
+            enc.SCHEDULE = "level"
+    assert out["dense"][1].shape[0] > 4000  # enough messages for the tiled kernel in the dense run
+    assert rel_err(out["level"][0], out["dense"][0]) < 2e-6
+    assert rel_err(out["level"][1], out["dense"][1]) < 2e-6
+    for n in out["dense"][2]:
+        assert fro_err(out["level"][2][n], out["dense"][2][n]) < 1e-5, n
+
+
+def test_training_scale_step_with_candidates_properties():
+    """The third configuration's shape (a few thousand molecules, candidate graphs included, forward +
+    backward through MPN, tree GRU and JTMPN): size-independent properties instead of an oracle run -
+    per-molecule / per-candidate vectors of the whole batch equal those of its two halves, everything
+    is finite, and every parameter on the path receives a gradient."""
+    from fast_jtnn_hip import synthetic, tensorize as T
+
+    class G:
+        pass
+    g = G()
+    B = 2048
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = 3, B, 450, 56, 20, 3, 385, 0.05
+    m = make_hip_model(g, "cuda")
+
+    def holders(trees):
+        synthetic.set_batch_nodeID(trees)
+        jt, mess_dict = T.jtenc_tensorize(trees)
+        mp = T.mpn_tensorize([t.mol for t in trees])
+        cands, _ = synthetic.collect_candidates(trees)
+        return jt, mp, T.jtmpn_tensorize(cands, mess_dict)
+
+    trees = synthetic.make_batch(3, B, vocab_size=385, with_cands=True)
+    jt, mp, cj = holders(trees)
+    tv, ms, mv = m.encode(jt, mp)
+    cv = m.jtmpn(*cj, ms)
+    assert cv.shape[0] > 4 * B and cv.shape[1] == 450
+    loss = (tv * tv).mean() + (mv * mv).mean() + (cv * cv).mean()
+    loss.backward()
+    for name, p in m.named_parameters():
+        if name.split(".")[0] in ("jtnn", "mpn", "jtmpn"):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+            assert float(p.grad.abs().max()) > 0.0, name
+    whole = [x.detach().cpu().numpy() for x in (tv, mv, cv)]
+    del tv, ms, mv, cv, loss
+    parts = []
+    with torch.no_grad():
+        for half in (trees[:B // 2], trees[B // 2:]):
+            jt_h, mp_h, cj_h = holders(half)
+            tv_h, ms_h, mv_h = m.encode(jt_h, mp_h)
+            parts.append([x.cpu().numpy() for x in (tv_h, mv_h, m.jtmpn(*cj_h, ms_h))])
+    for i, what in enumerate(("tree_vecs", "mol_vecs", "cand_vecs")):
+        both = np.concatenate([parts[0][i], parts[1][i]])
+        assert both.shape == whole[i].shape and np.isfinite(both).all(), what
+        assert rel_err(both, whole[i]) < 1e-5, what
