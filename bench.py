@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="print a per-shape GEMM table to stderr")
+    ap.add_argument("--mode", default="train", choices=("train", "encode"),
+                    help="train: forward + backward (the headline metric); encode: no-grad bulk encoding to "
+                         "[B, 900] vectors (latent generation), reported under its own metric name")
     ap.add_argument("--backend", default="nccl", help="collective backend; gloo lets several ranks rehearse the "
                                                       "N > 1 path on one GPU")
     args = ap.parse_args()
@@ -131,11 +134,17 @@ def main():
     model, jt, mp, stats = build_problem(seed=1234 + rank, batch=args.batch, vocab=args.vocab, device=device)
     bucket = parallel.FlatGradBucket([p for p in model.parameters() if p.requires_grad])
 
-    def step():
+    def train_step():
         bucket.zero()
         mean, logvar = model.encode_latent(jt, mp)
         (mean.sum() + logvar.sum()).backward()
         bucket.all_reduce_mean()
+
+    def encode_step():
+        with torch.no_grad():
+            model.encode_vectors(jt, mp)
+
+    step = train_step if args.mode == "train" else encode_step
 
     def barrier():
         if world > 1:
@@ -158,14 +167,16 @@ def main():
     value = args.batch * world * args.steps / elapsed
 
     out = {
-        "metric": "encoder fwd+bwd molecules/sec", "value": round(value, 1), "unit": "molecules/s",
+        "metric": "encoder fwd+bwd molecules/sec" if args.mode == "train" else "encoder no-grad encode molecules/sec",
+        "value": round(value, 1), "unit": "molecules/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic batch of %d molecular graphs per GPU (~40 atoms, <=6 neighbours): "
                                "MPN depthG=3 + JTNNEncoder/GraphGRU depthT=20, hidden 450, latent 56, "
-                               "forward + backward%s" % (args.batch, " + flat-bucket %s gradient all-reduce" %
+                               "%s%s" % (args.batch, "forward + backward" if args.mode == "train" else "forward only (no grad)",
+                                               " + flat-bucket %s gradient all-reduce" %
                                                          ("RCCL" if args.backend == "nccl" else args.backend)
-                                                         if world > 1 else ""),
+                                                         if world > 1 and args.mode == "train" else ""),
                    "molecules_per_gpu": args.batch, "global_batch": args.batch * world, "vocab": args.vocab,
                    "parallelism": "dp%d" % world, "grad_bucket_bytes": bucket.nbytes(), **stats},
     }
@@ -181,7 +192,7 @@ def main():
                 tf = d["flops"] / max(d["ms"], 1e-9) / 1e9
                 print("%-18s %-34s x%-3d %8.3f ms %7.1f TF" % (name, tag, d["launches"], d["ms"], tf), file=sys.stderr)
         kernels = []
-        traffic = pmc_traffic() if args.batch == 1024 else {}  # counters were taken on the default workload
+        traffic = pmc_traffic() if args.batch == 1024 and args.mode == "train" else {}  # counters were taken on the default workload
         for name, d in kt.summary().items():
             sec = d["ms"] * 1e-3
             if name in MFMA_KERNELS:

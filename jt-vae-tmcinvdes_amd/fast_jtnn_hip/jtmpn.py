@@ -53,7 +53,7 @@ class JTMPN(nn.Module):
             raise ValueError("feature widths %d/%d do not match W_i/W_o" % (prep.bond_in_fdim, prep.atom_fdim))
         with torch.cuda.device(device):
             return _GraphMPNFunction.apply(self.W_i.weight, self.W_h.weight, self.W_o.weight, self.W_o.bias,
-                                           tree_message, prep, self.depth)
+                                           tree_message, prep, self.depth, torch.is_grad_enabled())
 
     @staticmethod
     def tensorize(cand_batch, mess_dict):

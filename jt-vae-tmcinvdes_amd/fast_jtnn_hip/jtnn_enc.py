@@ -149,13 +149,14 @@ class _JTNNEncoderFunction(torch.autograd.Function):
     """forward(E, Wout, bout, Wz, bz, Wr, Ur, bu, Wh, bh) -> (tree_vecs [B,H], messages [NM,H])"""
 
     @staticmethod
-    def forward(ctx, E, Wout, bout, Wz, bz, Wr, Ur_w, bu, Wh, bh, prep, depth):
+    def forward(ctx, E, Wout, bout, Wz, bz, Wr, Ur_w, bu, Wh, bh, prep, depth, grad_on=True):
         dev = E.device
         H = Wr.shape[0]
         ld = K.round_ld(H)
         P = prep
         NM, B, NW = P.n_mess, P.n_trees, P.n_words
-        train = any(ctx.needs_input_grad)
+        # grad mode is off inside forward(): the caller's mode comes in as an argument
+        train = grad_on and any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)  # an unused output (messages in encode_latent) costs nothing
         sched = graphprep.tree_schedule(P, depth, dense=(SCHEDULE == "dense"))
 
@@ -275,7 +276,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
                          P.word_csr_t.col.data_ptr(), V, H, ld, nnz=NW)
         dE = torch.empty((V, H), dtype=torch.float32, device=dev)
         K.copy_rows(dE_p.data_ptr(), ld, dE.data_ptr(), H, V, H)
-        return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None
+        return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None, None
 
 
 class GraphGRU(nn.Module):
@@ -358,7 +359,7 @@ class JTNNEncoder(nn.Module):
         with torch.cuda.device(dev):
             return _JTNNEncoderFunction.apply(self.embedding.weight, lin.weight, lin.bias, g.W_z.weight,
                                               g.W_z.bias, g.W_r.weight, g.U_r.weight, g.U_r.bias,
-                                              g.W_h.weight, g.W_h.bias, prep, self.depth)
+                                              g.W_h.weight, g.W_h.bias, prep, self.depth, torch.is_grad_enabled())
 
     @staticmethod
     def tensorize(tree_batch):

@@ -102,14 +102,15 @@ class _GraphMPNFunction(torch.autograd.Function):
     """forward(W_i, W_h, W_o.weight, W_o.bias, tree_message | None) -> [n_seg, H]"""
 
     @staticmethod
-    def forward(ctx, W_i, W_h, W_o_w, W_o_b, tree_message, prep, depth):
+    def forward(ctx, W_i, W_h, W_o_w, W_o_b, tree_message, prep, depth, grad_on=True):
         dev = W_h.device
         H = W_h.shape[0]
         ld = K.round_ld(H)
         P = prep
         NB, NA, TM = P.n_bonds, P.n_atoms, P.n_tree
         fa_dim, fb_dim = P.atom_fdim, P.bond_in_fdim
-        train = any(ctx.needs_input_grad)
+        # grad mode is off inside forward(): the caller's mode comes in as an argument
+        train = grad_on and any(ctx.needs_input_grad)
 
         Wi, Wh, Woa, Woh = pack_weights([(W_i, 0, fb_dim, False), (W_h, 0, H, False), (W_o_w, 0, fa_dim, False),
                                          (W_o_w, fa_dim, H, False)])
@@ -215,7 +216,7 @@ class _GraphMPNFunction(torch.autograd.Function):
         dtree_out = None
         if TM and ctx.needs_input_grad[4]:
             dtree_out = dense_view(dtree, H)
-        return dW_i, dW_h, dW_o, db_o, dtree_out, None, None
+        return dW_i, dW_h, dW_o, db_o, dtree_out, None, None, None
 
 
 def _holder_prep(fatoms, fbonds, agraph, bgraph, scope, device, n_tree):
@@ -247,7 +248,7 @@ class MPN(nn.Module):
             raise ValueError("feature widths %d/%d do not match W_i/W_o" % (prep.bond_in_fdim, prep.atom_fdim))
         with torch.cuda.device(device):
             return _GraphMPNFunction.apply(self.W_i.weight, self.W_h.weight, self.W_o.weight, self.W_o.bias,
-                                           None, prep, self.depth)
+                                           None, prep, self.depth, torch.is_grad_enabled())
 
     @staticmethod
     def tensorize(mol_batch):
