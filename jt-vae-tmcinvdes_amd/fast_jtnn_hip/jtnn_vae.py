@@ -57,14 +57,43 @@ class JTNNVAE(nn.Module):
         self.G_mean = nn.Linear(hidden_size, latent_size)
         self.G_var = nn.Linear(hidden_size, latent_size)
 
+    # The tree encoder and the graph encoder share nothing until their outputs meet, and the tail
+    # iterations of the tree GRU are short launches that leave most of the GPU idle: on a GPU the
+    # two can run on two side streams, so that the graph encoder's large GEMMs fill those gaps (autograd
+    # replays each backward on the stream of its forward, so the backward passes overlap as well).
+    # Results are bit-identical to the one-stream order.  Off by default: the reference issues
+    # everything on one stream, and per-kernel timings are only meaningful without co-running kernels.
+    overlap_streams = False
+
+    def _side_streams(self, device):
+        cache = self.__dict__.setdefault("_stream_cache", {})
+        key = (device.type, device.index)
+        if key not in cache:
+            cache[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return cache[key]
+
     def encode(self, jtenc_holder, mpn_holder):  # jtnn_vae.py:45-48
-        tree_vecs, tree_mess = self.jtnn(*jtenc_holder)
-        mol_vecs = self.mpn(*mpn_holder)
+        device = self.mpn.W_h.weight.device
+        if not (self.overlap_streams and device.type == "cuda"):
+            tree_vecs, tree_mess = self.jtnn(*jtenc_holder)
+            mol_vecs = self.mpn(*mpn_holder)
+            return tree_vecs, tree_mess, mol_vecs
+        s_tree, s_graph = self._side_streams(device)
+        cur = torch.cuda.current_stream(device)
+        s_tree.wait_stream(cur)
+        s_graph.wait_stream(cur)
+        with torch.cuda.stream(s_tree):
+            tree_vecs, tree_mess = self.jtnn(*jtenc_holder)
+        with torch.cuda.stream(s_graph):
+            mol_vecs = self.mpn(*mpn_holder)
+        cur.wait_stream(s_tree)
+        cur.wait_stream(s_graph)
+        for t in (tree_vecs, tree_mess, mol_vecs):  # allocated on a side stream, consumed on the caller's
+            t.record_stream(cur)
         return tree_vecs, tree_mess, mol_vecs
 
     def encode_latent(self, jtenc_holder, mpn_holder):  # jtnn_vae.py:56-65
-        tree_vecs, _ = self.jtnn(*jtenc_holder)
-        mol_vecs = self.mpn(*mpn_holder)
+        tree_vecs, _, mol_vecs = self.encode(jtenc_holder, mpn_holder)
         tree_mean = self.T_mean(tree_vecs)
         mol_mean = self.G_mean(mol_vecs)
         tree_var = -torch.abs(self.T_var(tree_vecs))
