@@ -56,7 +56,6 @@ extern "C" __device__ unsigned long long* jtvae_trace_buf = nullptr;  // [blocks
 namespace {
 
 constexpr int NT_BM = 128;
-constexpr int NT_BN = 96;
 constexpr int NT_BK = 32;
 constexpr int NT_LDS = 36;  // floats per LDS row: 32 + 4 -> ds_read_b128 of 16 rows hits 16 distinct 16-B slots
 
