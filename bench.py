@@ -192,7 +192,7 @@ def main():
         with K.KernelTimer() as kt:
             step()
         if args.detail:
-            for (name, tag), d in sorted(kt.detail().items(), key=lambda kv: -kv[1]["ms"])[:40]:
+            for (name, tag), d in sorted(kt.detail().items(), key=lambda kv: -kv[1]["ms"])[:200]:
                 tf = d["flops"] / max(d["ms"], 1e-9) / 1e9
                 print("%-18s %-34s x%-3d %8.3f ms %7.1f TF" % (name, tag, d["launches"], d["ms"], tf), file=sys.stderr)
         kernels = []

@@ -120,15 +120,6 @@ def upload_csr(rowptr: np.ndarray, col: np.ndarray, device) -> DeviceCSR:
     return DeviceCSR(_dev_i32(rowptr, device), col_t, int(rowptr.shape[0] - 1), int(col.shape[0]))
 
 
-def pad_cols(x: np.ndarray, mult: int = 4) -> np.ndarray:
-    """Zero-pad the feature columns to a multiple of ``mult`` (16-byte rows for float32)."""
-    n, f = x.shape
-    fp = (f + mult - 1) // mult * mult
-    out = np.zeros((n, fp), dtype=np.float32)
-    out[:, :f] = x
-    return out
-
-
 def _upload_features(x: np.ndarray, device) -> torch.Tensor:
     """[n, f] float32 -> device [n, round4(f)] with zero padding columns; the padding is added on the
     device, so the host only hands over the array it already has."""

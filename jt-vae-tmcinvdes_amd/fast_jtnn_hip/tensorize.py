@@ -105,9 +105,8 @@ def jtenc_tensorize_nodes(node_batch: Sequence, scope):
     # mess_graph[(y->z)] lists messages (x->y), x != z, in message order of (x->y):
     # pair every message m1=(x->y) with the outgoing messages of y
     if xs.size:
-        first_out = np.zeros(n_nodes + 1, dtype=np.int64)  # outgoing messages of a node are consecutive ids
-        np.cumsum(np.bincount(xs, minlength=n_nodes), out=first_out[1:])
-        # messages were numbered node by node only if node_batch is in idx order; map idx -> first id generally
+        # outgoing messages of a node are consecutive ids, numbered node by node in batch order:
+        # map a node's idx to the id of its first outgoing message
         order_nodes = np.asarray([x.idx for x in node_batch], dtype=np.int64)
         out_cnt = np.asarray([len(x.neighbors) for x in node_batch], dtype=np.int64)
         start_by_pos = np.concatenate([[0], np.cumsum(out_cnt)[:-1]]) + 1
