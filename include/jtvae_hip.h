@@ -229,6 +229,14 @@ int jtvae_select_slab_rows(float* out, const float* base, size_t slab_stride, co
 int jtvae_row_dot(float* score, const float* q, const int32_t* owner, const float* cand,
                   int32_t n_cand, int32_t H, int32_t ld, void* stream);
 
+/* Candidate-assembly loss: segment s covers scores[seg_ptr[s] .. seg_ptr[s+1]) (the candidates of one
+ * tree node), label_pos[s] is the index of the true candidate.  loss_seg[s] = cross entropy of the
+ * segment, hit_seg[s] = 1 if the label has the highest score, dscores (or NULL) = softmax - onehot.
+ * Replaces the per-node narrow + CrossEntropyLoss + .item() loop of fast_jtnn/jtnn_vae.py:116-135
+ * (jtprop_vae.py:454-473). */
+int jtvae_segment_ce(const float* scores, const int32_t* seg_ptr, const int32_t* label_pos, int32_t n_seg,
+                     float* loss_seg, int32_t* hit_seg, float* dscores, void* stream);
+
 /* ---- host-side index preparation (host memory in and out; no GPU work, no stream) ---------- */
 
 /* A zero-padded int64 neighbour table [rows, K] (agraph / bgraph of fast_jtnn/mpn.py:148-159 and

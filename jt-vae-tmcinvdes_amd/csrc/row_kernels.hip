@@ -191,6 +191,31 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackArgs a) {
   }
 }
 
+// Candidate-assembly loss (fast_jtnn/jtnn_vae.py:116-135): per tree node one cross entropy over the
+// scores of its candidates.  One thread per segment (a node has a handful of candidates): loss, whether
+// the label scores highest, and d(loss)/d(score) = softmax - onehot for the backward pass.
+__global__ __launch_bounds__(JTVAE_BLOCK) void segment_ce_kernel(const float* __restrict__ scores,
+                                                                 const int* __restrict__ seg_ptr,
+                                                                 const int* __restrict__ label_pos, int n_seg,
+                                                                 float* __restrict__ loss_seg,
+                                                                 int* __restrict__ hit_seg,
+                                                                 float* __restrict__ dscores) {
+  int sgm = blockIdx.x * JTVAE_BLOCK + threadIdx.x;
+  if (sgm >= n_seg) return;
+  const int b = seg_ptr[sgm], e = seg_ptr[sgm + 1], lab = label_pos[sgm];
+  float mx = -INFINITY;
+  for (int i = b; i < e; ++i) mx = fmaxf(mx, scores[i]);
+  float den = 0.f;
+  for (int i = b; i < e; ++i) den += expf(scores[i] - mx);
+  const float sl = scores[lab];
+  loss_seg[sgm] = logf(den) + mx - sl;
+  hit_seg[sgm] = sl >= mx ? 1 : 0;
+  if (dscores) {
+    const float inv = 1.f / den;
+    for (int i = b; i < e; ++i) dscores[i] = expf(scores[i] - mx) * inv - (i == lab ? 1.f : 0.f);
+  }
+}
+
 // score[c] = <q[owner[c]], cand[c]>, one wave per candidate
 __global__ __launch_bounds__(JTVAE_BLOCK) void row_dot_kernel(float* __restrict__ score,
                                                               const float* __restrict__ q,
@@ -357,6 +382,16 @@ int jtvae_row_dot(float* score, const float* q, const int32_t* owner, const floa
   long total = (long)n_cand * 64;
   hipLaunchKernelGGL(row_dot_kernel, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, score, q,
                      owner, cand, n_cand, ld / 4, H, ld);
+  return launch_status();
+}
+
+int jtvae_segment_ce(const float* scores, const int32_t* seg_ptr, const int32_t* label_pos, int32_t n_seg,
+                     float* loss_seg, int32_t* hit_seg, float* dscores, void* stream) {
+  if (n_seg < 0) return JTVAE_E_SHAPE;
+  if (n_seg == 0) return 0;
+  if (!scores || !seg_ptr || !label_pos || !loss_seg || !hit_seg) return JTVAE_E_NULL;
+  hipLaunchKernelGGL(segment_ce_kernel, dim3(grid_for(n_seg)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, scores,
+                     seg_ptr, label_pos, n_seg, loss_seg, hit_seg, dscores);
   return launch_status();
 }
 

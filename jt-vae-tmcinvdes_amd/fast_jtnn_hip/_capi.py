@@ -79,6 +79,7 @@ SIGNATURES = {
     "jtvae_colsum": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "jtvae_pack_batch": (C.c_int, [C.POINTER(PackItem), _i32, _vp]),
     "jtvae_transpose": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_segment_ce": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "jtvae_prep_padded_to_csr": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
     "jtvae_prep_transpose_csr": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_stable_from": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
@@ -320,6 +321,11 @@ def gru_bwd_gather(h, Uh, slab_stride, t_iter, sf, active, Pr, wid, dg, ds, trow
 def select_slab_rows(out, base, slab_stride, sel, n_rows, H, ld):
     _run("select_slab_rows", lib.jtvae_select_slab_rows, (out, base, slab_stride, sel, n_rows, H, ld, stream_ptr()),
          nbytes=8 * H * n_rows + 4 * n_rows)
+
+
+def segment_ce(scores, seg_ptr, label_pos, n_seg, loss_seg, hit_seg, dscores, n_scores=0):
+    _run("segment_ce", lib.jtvae_segment_ce, (scores, seg_ptr, label_pos, n_seg, loss_seg, hit_seg, dscores,
+                                              stream_ptr()), nbytes=8 * n_scores + 16 * n_seg)
 
 
 def row_dot(score, q, owner, cand, n_cand, H, ld):

@@ -19,23 +19,44 @@ from .jtnn_enc import JTNNEncoder
 from .mpn import MPN
 
 
+class _SegmentCE(torch.autograd.Function):
+    """scores [NC], seg_ptr int32 [S+1], label_pos int32 [S] -> (loss sum, hits): one kernel forward,
+    one multiply backward."""
+
+    @staticmethod
+    def forward(ctx, scores, seg_ptr, label_pos):
+        from . import _capi as K
+        S = label_pos.shape[0]
+        sc = scores.detach().contiguous().float()
+        loss_seg = torch.empty((S,), dtype=torch.float32, device=sc.device)
+        hit_seg = torch.empty((S,), dtype=torch.int32, device=sc.device)
+        dsc = torch.empty_like(sc)
+        with torch.cuda.device(sc.device):
+            K.segment_ce(sc.data_ptr(), seg_ptr.data_ptr(), label_pos.data_ptr(), S, loss_seg.data_ptr(),
+                         hit_seg.data_ptr(), dsc.data_ptr(), n_scores=sc.shape[0])
+        ctx.save_for_backward(dsc)
+        ctx.mark_non_differentiable(hit_seg)
+        return loss_seg.sum(), hit_seg
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        (dsc,) = ctx.saved_tensors
+        return dsc * dloss, None, None
+
+
 def segment_cross_entropy(scores: torch.Tensor, seg_len: torch.Tensor, label_pos: torch.Tensor):
     """Sum over segments of CrossEntropy(scores[segment], label) and the number of segments
-    whose label scores highest - the loop of fast_jtnn/jtnn_vae.py:116-135 without one launch
-    and one host sync per tree node.
+    whose label scores highest - the loop of fast_jtnn/jtnn_vae.py:116-135 as one kernel, without
+    one launch and one host sync per tree node.
 
     scores [NC]; seg_len [S] candidates per node (consecutive); label_pos [S] global index of the label.
     """
-    S = seg_len.shape[0]
-    seg_id = torch.repeat_interleave(torch.arange(S, device=scores.device), seg_len)
-    smax = torch.full((S,), float("-inf"), device=scores.device, dtype=scores.dtype)
-    smax = smax.scatter_reduce(0, seg_id, scores.detach(), reduce="amax")
-    ex = torch.exp(scores - smax[seg_id])
-    denom = torch.zeros(S, device=scores.device, dtype=scores.dtype).index_add(0, seg_id, ex)
-    lab = scores[label_pos]
-    loss = (torch.log(denom) + smax - lab).sum()
-    acc = (lab.detach() >= smax).sum()
-    return loss, acc
+    if scores.device.type != "cuda":
+        raise RuntimeError("segment_cross_entropy runs on the GPU only (got %s)" % scores.device)
+    seg_ptr = torch.zeros(seg_len.shape[0] + 1, dtype=torch.int32, device=scores.device)
+    seg_ptr[1:] = torch.cumsum(seg_len.to(scores.device), 0)
+    loss, hits = _SegmentCE.apply(scores, seg_ptr, label_pos.to(device=scores.device, dtype=torch.int32))
+    return loss, hits.sum()
 
 
 class JTNNVAE(nn.Module):

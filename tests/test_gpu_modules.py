@@ -376,3 +376,33 @@ def test_training_scale_step_with_candidates_properties():
         both = np.concatenate([parts[0][i], parts[1][i]])
         assert both.shape == whole[i].shape and np.isfinite(both).all(), what
         assert rel_err(both, whole[i]) < 1e-5, what
+
+
+def test_assembly_loss_matches_reference_loop():
+    """segment_cross_entropy (one kernel) against the reference's formulation: per tree node a
+    CrossEntropyLoss(sum) over that node's candidate scores, and a count of nodes whose label scores
+    highest (fast_jtnn/jtnn_vae.py:116-135) - loss, accuracy count and the gradient of the scores."""
+    from fast_jtnn_hip.jtnn_vae import segment_cross_entropy
+    rs = np.random.RandomState(4)
+    seg_len = rs.randint(2, 12, size=300)
+    seg_len[:5] = [2, 2, 40, 3, 97]  # long segments too
+    starts = np.concatenate([[0], np.cumsum(seg_len)[:-1]])
+    label = starts + np.array([rs.randint(0, n) for n in seg_len])
+    scores_np = (rs.standard_normal(int(seg_len.sum())) * 3).astype(np.float32)
+    scores_np[label[7]] = scores_np[starts[7]:starts[7] + seg_len[7]].max()  # a tie counts as a hit (>=)
+
+    ref_scores = torch.tensor(scores_np, dtype=torch.float64, requires_grad=True)
+    ce = torch.nn.CrossEntropyLoss(reduction="sum")
+    ref_loss, ref_hits = 0.0, 0
+    for st, n, lab in zip(starts, seg_len, label):
+        seg = ref_scores.narrow(0, int(st), int(n))
+        ref_loss = ref_loss + ce(seg.view(1, -1), torch.tensor([int(lab - st)]))
+        ref_hits += int(seg[int(lab - st)].item() >= seg.max().item())
+    ref_loss.backward()
+
+    sc = torch.tensor(scores_np, device="cuda", requires_grad=True)
+    loss, hits = segment_cross_entropy(sc, torch.tensor(seg_len, device="cuda"), torch.tensor(label, device="cuda"))
+    (loss * 0.5).backward()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item())
+    assert int(hits.item()) == ref_hits
+    assert rel_err(sc.grad.cpu().numpy(), 0.5 * ref_scores.grad.numpy()) < 1e-5
