@@ -90,6 +90,23 @@ const char* jtvae_error_string(int code);
 int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc,
                   int32_t M, int32_t N, int32_t K, const jtvae_epilogue_t* epi, void* stream);
 
+/* Two independent NT products (neither reads what the other writes) issued together: when both are
+ * small or mid-size and carry the epilogue pair of the tree GRU's backward pass (first PLAIN, second
+ * MUL_ACC: ds += dz.Wz and dg = dp.Wh with its reset-gate accumulation, the autograd of
+ * fast_jtnn/jtnn_enc.py:115,124) they run as ONE launch and share the otherwise idle CUs; any other
+ * combination runs as two launches.  Results are those of two jtvae_gemm_nt calls. */
+typedef struct jtvae_gemm_nt_problem {
+  const float* A;
+  int32_t lda;
+  const float* W;
+  int32_t ldw;
+  float* C;
+  int32_t ldc;
+  int32_t M, N, K;
+  const jtvae_epilogue_t* epi; /* NULL = plain product */
+} jtvae_gemm_nt_problem_t;
+int jtvae_gemm_nt_pair(const jtvae_gemm_nt_problem_t* p0, const jtvae_gemm_nt_problem_t* p1, void* stream);
+
 /* dW[N,K] (+)= sum_m X[xr(m), 0:N]^T . Y[yr(m), 0:K]  - the weight gradient of C = Y.W^T given
  * X = dC, reduced over M in fixed order (split-M slabs + ordered slab sum: bitwise reproducible, no
  * atomics).  x_rows / y_rows (int32 [M], or NULL = identity) pick the row of X and of Y for every

@@ -273,9 +273,8 @@ constexpr int NT_EPI_LD = 40;  // LDS row stride of a wave's 32 x 32 staging til
 // (128 x 32) for mid-size launches, where three times as many, shorter-lived blocks cut the latency
 // chain of a block that has a CU to itself.
 template <bool VEC, int MODE, bool EVEC, int NACC>
-__global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
+__device__ __forceinline__ void gemm_nt_body(const NtArgs& a, const int block_id, float* smem) {
   constexpr int BN = 32 * NACC;
-  __shared__ __attribute__((aligned(16))) float smem[(NT_BM + BN) * NT_LDS];
   static_assert(4 * 32 * NT_EPI_LD <= (NT_BM + BN) * NT_LDS, "epilogue staging must fit the operand tiles");
   float* As = smem;
   float* Bs = smem + NT_BM * NT_LDS;
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int tile = xcd_remap(blockIdx.x, a.n_blocks);
+  const int tile = xcd_remap(block_id, a.n_blocks);
   const int m0 = (tile / a.n_tiles_n) * NT_BM;
   const int n0 = (tile % a.n_tiles_n) * BN;
   const jtvae_epilogue_t& e = a.e;
@@ -424,6 +423,23 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   TRACE_MARK(80);  // results written
 }
 
+template <bool VEC, int MODE, bool EVEC, int NACC>
+__global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[(NT_BM + 32 * NACC) * NT_LDS];
+  gemm_nt_body<VEC, MODE, EVEC, NACC>(a, blockIdx.x, smem);
+}
+
+// Two independent products in one launch (blocks [0, a.n_blocks) serve the first): mid-size launches
+// leave most CUs idle, so two of them that do not depend on each other share the chip.
+template <int MODE_A, int MODE_B, int NACC>
+__global__ __launch_bounds__(256, 4) void gemm_nt_pair_kernel(NtArgs a, NtArgs b) {
+  __shared__ __attribute__((aligned(16))) float smem[(NT_BM + 32 * NACC) * NT_LDS];
+  if ((int)blockIdx.x < a.n_blocks)
+    gemm_nt_body<true, MODE_A, true, NACC>(a, blockIdx.x, smem);
+  else
+    gemm_nt_body<true, MODE_B, true, NACC>(b, blockIdx.x - a.n_blocks, smem);
+}
+
 // ---------------------------------------------------------------------------------------
 // Small-M variant.  The tail iterations of the tree GRU touch a few to a few hundred rows; with
 // the tiled kernel such a launch is one or two blocks walking 15 dependent K tiles (load ->
@@ -437,13 +453,12 @@ constexpr int SM_C4 = SM_KMAX / 4;         // float4 per staged row
 constexpr int SM_PER_THREAD = (32 * SM_C4 + 255) / 256;
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void gemm_nt_small_kernel(NtArgs a) {
-  __shared__ __attribute__((aligned(16))) float sm[2 * 32 * SM_LD];  // 115 KiB: one block per CU
+__device__ __forceinline__ void gemm_nt_small_body(const NtArgs& a, const int block_id, float* sm) {
   float* As = sm;
   float* Ws = sm + 32 * SM_LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = (blockIdx.x / a.n_tiles_n) * 32;
-  const int n0 = (blockIdx.x % a.n_tiles_n) * 32;
+  const int m0 = (block_id / a.n_tiles_n) * 32;
+  const int n0 = (block_id % a.n_tiles_n) * 32;
   const jtvae_epilogue_t& e = a.e;
   const int c4n = (a.K + 3) >> 2;  // float4 per row that hold data
 
@@ -510,6 +525,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_small_kernel(NtArgs a) {
       for (int j = 0; j < 4; ++j) epi_store<MODE>(a, R, n0 + nq + j, v[j]);
     }
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void gemm_nt_small_kernel(NtArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * 32 * SM_LD];  // 115 KiB: one block per CU
+  gemm_nt_small_body<MODE>(a, blockIdx.x, sm);
+}
+
+template <int MODE_A, int MODE_B>
+__global__ __launch_bounds__(256, 1) void gemm_nt_small_pair_kernel(NtArgs a, NtArgs b) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * 32 * SM_LD];
+  if ((int)blockIdx.x < a.n_blocks)
+    gemm_nt_small_body<MODE_A>(a, blockIdx.x, sm);
+  else
+    gemm_nt_small_body<MODE_B>(b, blockIdx.x - a.n_blocks, sm);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -723,6 +753,7 @@ constexpr int SM_MAX_ROWS = 512;  // above this the tiled kernel fills the chip 
 void launch_nt_small(NtArgs a, hipStream_t s) {
   a.n_tiles_n = (a.N + 31) / 32;
   const int blocks = ((a.M + 31) / 32) * a.n_tiles_n;
+  a.n_blocks = blocks;
   switch (a.e.mode) {
     case JTVAE_EPI_GRU_BLEND:
       hipLaunchKernelGGL((gemm_nt_small_kernel<JTVAE_EPI_GRU_BLEND>), dim3(blocks), dim3(256), 0, s, a);
@@ -774,19 +805,17 @@ bool epilogue_aligned(const NtArgs& a) {
   return true;
 }
 
-}  // namespace
-
-extern "C" {
-
-int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc, int32_t M,
-                  int32_t N, int32_t K, const jtvae_epilogue_t* epi, void* stream) {
+// argument checks and kernel arguments of one NT product; vec = operands are float4-addressable
+int nt_setup(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc, int32_t M, int32_t N,
+             int32_t K, const jtvae_epilogue_t* epi, NtArgs& a, bool& vec) {
+  vec = false;
   if (M < 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldc < N) return JTVAE_E_SHAPE;
   if (M == 0) return 0;
   if (!A || !W || !C) return JTVAE_E_NULL;
-  NtArgs a;
   a.A = A; a.W = W; a.C = C;
   a.lda = lda; a.ldw = ldw; a.ldc = ldc;
   a.M = M; a.N = N; a.K = K;
+  a.n_tiles_n = 0; a.n_blocks = 0;
   if (epi) {
     a.e = *epi;
   } else {
@@ -800,12 +829,16 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
   if (e.mode == JTVAE_EPI_GRU_BLEND && (!e.aux0 || !e.aux1 || !e.out2 || e.ld_aux < N)) return JTVAE_E_NULL;
   if (e.mode == JTVAE_EPI_MUL_ACC && (!e.aux0 || !e.out2 || e.ld_aux < N)) return JTVAE_E_NULL;
   if (e.aux_sf && e.aux_t < 0) return JTVAE_E_SHAPE;
-  const bool vec = aligned16(A, lda) && aligned16(W, ldw);
+  vec = aligned16(A, lda) && aligned16(W, ldw);
   a.evec = epilogue_aligned(a) ? 1 : 0;
-  hipStream_t s = (hipStream_t)stream;
-  if (vec && M <= SM_MAX_ROWS && K <= SM_KMAX)
+  return 0;
+}
+
+// picks the kernel for one product by its row count and operand alignment
+void launch_nt_any(const NtArgs& a, bool vec, hipStream_t s) {
+  if (vec && a.M <= SM_MAX_ROWS && a.K <= SM_KMAX)
     launch_nt_small(a, s);
-  else if (vec && a.evec && M <= narrow_max_rows())
+  else if (vec && a.evec && a.M <= narrow_max_rows())
     launch_nt<true, true, 1>(a, s);
   else if (vec && a.evec)
     launch_nt<true, true, 3>(a, s);
@@ -813,6 +846,54 @@ int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, floa
     launch_nt<true, false, 3>(a, s);
   else
     launch_nt<false, false, 3>(a, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int jtvae_gemm_nt(const float* A, int32_t lda, const float* W, int32_t ldw, float* C, int32_t ldc, int32_t M,
+                  int32_t N, int32_t K, const jtvae_epilogue_t* epi, void* stream) {
+  NtArgs a;
+  bool vec;
+  const int rc = nt_setup(A, lda, W, ldw, C, ldc, M, N, K, epi, a, vec);
+  if (rc != 0 || M == 0) return rc;
+  launch_nt_any(a, vec, (hipStream_t)stream);
+  return launch_status();
+}
+
+int jtvae_gemm_nt_pair(const jtvae_gemm_nt_problem_t* p0, const jtvae_gemm_nt_problem_t* p1, void* stream) {
+  if (!p0 || !p1) return JTVAE_E_NULL;
+  NtArgs a, b;
+  bool vec_a, vec_b;
+  int rc = nt_setup(p0->A, p0->lda, p0->W, p0->ldw, p0->C, p0->ldc, p0->M, p0->N, p0->K, p0->epi, a, vec_a);
+  if (rc != 0) return rc;
+  rc = nt_setup(p1->A, p1->lda, p1->W, p1->ldw, p1->C, p1->ldc, p1->M, p1->N, p1->K, p1->epi, b, vec_b);
+  if (rc != 0) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  // one launch for the combination the tree GRU's backward pass issues (plain + multiply-accumulate
+  // epilogue) when both products are small or mid-size; anything else runs as two launches
+  const bool combo = a.e.mode == JTVAE_EPI_PLAIN && b.e.mode == JTVAE_EPI_MUL_ACC && vec_a && vec_b &&
+                     p0->M > 0 && p1->M > 0;
+  const int big = p0->M > p1->M ? p0->M : p1->M;
+  if (combo && big <= SM_MAX_ROWS && a.K <= SM_KMAX && b.K <= SM_KMAX) {
+    a.n_tiles_n = (a.N + 31) / 32;
+    a.n_blocks = ((a.M + 31) / 32) * a.n_tiles_n;
+    b.n_tiles_n = (b.N + 31) / 32;
+    b.n_blocks = ((b.M + 31) / 32) * b.n_tiles_n;
+    hipLaunchKernelGGL((gemm_nt_small_pair_kernel<JTVAE_EPI_PLAIN, JTVAE_EPI_MUL_ACC>), dim3(a.n_blocks + b.n_blocks),
+                       dim3(256), 0, s, a, b);
+  } else if (combo && a.evec && b.evec && big <= narrow_max_rows()) {
+    a.n_tiles_n = (a.N + 31) / 32;
+    a.n_blocks = ((a.M + NT_BM - 1) / NT_BM) * a.n_tiles_n;
+    b.n_tiles_n = (b.N + 31) / 32;
+    b.n_blocks = ((b.M + NT_BM - 1) / NT_BM) * b.n_tiles_n;
+    hipLaunchKernelGGL((gemm_nt_pair_kernel<JTVAE_EPI_PLAIN, JTVAE_EPI_MUL_ACC, 1>), dim3(a.n_blocks + b.n_blocks),
+                       dim3(256), 0, s, a, b);
+  } else {
+    if (p0->M > 0) launch_nt_any(a, vec_a, s);
+    if (p1->M > 0) launch_nt_any(b, vec_b, s);
+  }
   return launch_status();
 }
 

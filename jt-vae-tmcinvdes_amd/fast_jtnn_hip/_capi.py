@@ -51,6 +51,21 @@ class Epilogue(C.Structure):
     ]
 
 
+class NtProblem(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p),
+        ("lda", C.c_int32),
+        ("W", C.c_void_p),
+        ("ldw", C.c_int32),
+        ("C", C.c_void_p),
+        ("ldc", C.c_int32),
+        ("M", C.c_int32),
+        ("N", C.c_int32),
+        ("K", C.c_int32),
+        ("epi", C.POINTER(Epilogue)),
+    ]
+
+
 class PackItem(C.Structure):
     _fields_ = [
         ("src", C.c_void_p),
@@ -72,6 +87,7 @@ SIGNATURES = {
     "jtvae_abi_version": (C.c_int, []),
     "jtvae_error_string": (C.c_char_p, [C.c_int]),
     "jtvae_gemm_nt": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, C.POINTER(Epilogue), _vp]),
+    "jtvae_gemm_nt_pair": (C.c_int, [C.POINTER(NtProblem), C.POINTER(NtProblem), _vp]),
     "jtvae_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "jtvae_gemm_tn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _sz,
                                 _vp]),
@@ -226,6 +242,34 @@ def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0
     _run("gemm_nt", lib.jtvae_gemm_nt, (A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()),
          nbytes=4 * (M * K + N * K + M * N * (1 + extra)), flops=2 * M * N * K,
          tag="M=%d N=%d K=%d mode=%d" % (M, N, K, mode))
+
+
+def nt_problem(A, lda, W, ldw, Cout, ldc, M, N, K, **epi):
+    """Arguments of one gemm_nt call, for gemm_nt_pair (keyword arguments as in gemm_nt)."""
+    names = ("bias", "add", "ld_add", "add_idx", "act", "pre_out", "ld_pre", "mode", "aux0", "aux1", "out2", "ld_aux",
+             "a_rows", "c_rows", "zero_row", "aux_sf", "aux_t", "aux_slab_stride")
+    defaults = dict(bias=None, add=None, ld_add=0, add_idx=None, act=ACT_NONE, pre_out=None, ld_pre=0, mode=EPI_PLAIN,
+                    aux0=None, aux1=None, out2=None, ld_aux=0, a_rows=None, c_rows=None, zero_row=-1, aux_sf=None,
+                    aux_t=0, aux_slab_stride=0)
+    unknown = set(epi) - set(names)
+    if unknown:
+        raise TypeError("unknown epilogue arguments %s" % sorted(unknown))
+    defaults.update(epi)
+    e = Epilogue(*[defaults[n] for n in names])
+    p = NtProblem(A, lda, W, ldw, Cout, ldc, M, N, K, C.pointer(e))
+    p._keep = e  # the problem points at its epilogue
+    return p
+
+
+def gemm_nt_pair(p0, p1):
+    """Two independent products (see nt_problem) in one launch where the library supports the pair."""
+    def price(p):
+        e = p._keep
+        extra = (1 if e.add else 0) + (1 if e.pre_out else 0) + (3 if e.mode != EPI_PLAIN else 0)
+        return 4 * (p.M * p.K + p.N * p.K + p.M * p.N * (1 + extra)), 2 * p.M * p.N * p.K
+    (b0, f0), (b1, f1) = price(p0), price(p1)
+    _run("gemm_nt", lib.jtvae_gemm_nt_pair, (C.byref(p0), C.byref(p1), stream_ptr()), nbytes=b0 + b1, flops=f0 + f1,
+         tag="pair M=%d+%d N=%d K=%d" % (p0.M, p1.M, p0.N, p0.K))
 
 
 def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device, x_rows=None, y_rows=None, dbias=None):

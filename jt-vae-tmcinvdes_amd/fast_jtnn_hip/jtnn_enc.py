@@ -115,13 +115,15 @@ class _TreeGRU:
             if t == 0:
                 break
             J = bs.J[t]
-            # ds += dzpre W_z[:, H:]
-            K.gemm_nt(dz_t, ld, WzhT.data_ptr(), ld, ds.data_ptr(), ld, E.n, H, H, add=ds.data_ptr(), ld_add=ld,
-                      c_rows=E.ptr())
-            # dg = dppre W_h[:, H:];  A_r += dg * t   (gradient reaching W_r x through the reset gate)
-            K.gemm_nt(dp_t, ld, WhhT.data_ptr(), ld, dg.data_ptr(), ld, E.n, H, H, mode=K.EPI_MUL_ACC,
-                      aux0=ts.data_ptr(), out2=a_r.data_ptr(), ld_aux=ld, c_rows=E.ptr(), aux_sf=sf_p, aux_t=t,
-                      aux_slab_stride=stride)
+            # two independent products, issued together:
+            #   ds += dzpre W_z[:, H:]
+            #   dg = dppre W_h[:, H:];  A_r += dg * t   (gradient reaching W_r x through the reset gate)
+            K.gemm_nt_pair(
+                K.nt_problem(dz_t, ld, WzhT.data_ptr(), ld, ds.data_ptr(), ld, E.n, H, H, add=ds.data_ptr(), ld_add=ld,
+                             c_rows=E.ptr()),
+                K.nt_problem(dp_t, ld, WhhT.data_ptr(), ld, dg.data_ptr(), ld, E.n, H, H, mode=K.EPI_MUL_ACC,
+                             aux0=ts.data_ptr(), out2=a_r.data_ptr(), ld_aux=ld, c_rows=E.ptr(), aux_sf=sf_p, aux_t=t,
+                             aux_slab_stride=stride))
             if J.n == 0:
                 break
             du_t = K.ptr(du, bs.offJ[t] * ld)

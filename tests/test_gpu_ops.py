@@ -449,3 +449,39 @@ def test_row_list_variants(K):
     K.select_slab_rows(out.data_ptr(), hsd.data_ptr(), NM * ld, dev(sel).data_ptr(), NM, H, ld)
     torch.cuda.synchronize()
     assert np.array_equal(out[:, :H].cpu().numpy(), hs[sel, np.arange(NM)])
+
+
+@pytest.mark.parametrize("M0,M1", [(200, 200), (300, 77), (3000, 3000), (900, 5000), (20000, 20000), (0, 100)])
+def test_gemm_nt_pair_equals_two_calls(K, M0, M1):
+    """The paired launch (accumulate-in-place product + multiply-accumulate product, the pair of the
+    tree GRU's backward pass) gives exactly what two separate calls give, at every size class."""
+    rs = np.random.RandomState(M0 + M1)
+    H, ld = 450, 452
+    Wa = dev_rows(rs.standard_normal((H, H)).astype(np.float32) * 0.1, ld)
+    Wb = dev_rows(rs.standard_normal((H, H)).astype(np.float32) * 0.1, ld)
+    NM = max(M0, M1, 1) + 50
+    rows0 = dev(np.sort(rs.choice(NM, size=M0, replace=False)).astype(np.int32)) if M0 else None
+    rows1 = dev(np.sort(rs.choice(NM, size=M1, replace=False)).astype(np.int32)) if M1 else None
+    A0 = dev_rows(rs.standard_normal((max(M0, 1), H)).astype(np.float32), ld)
+    A1 = dev_rows(rs.standard_normal((max(M1, 1), H)).astype(np.float32), ld)
+    mul = dev_rows(rs.standard_normal((NM, H)).astype(np.float32), ld)
+    out = {}
+    for how in ("pair", "two"):
+        ds = dev_rows(np.ones((NM, H), np.float32), ld)
+        dg = dev_rows(np.zeros((NM, H), np.float32), ld)
+        acc = dev_rows(np.full((NM, H), 0.5, np.float32), ld)
+        a0 = dict(add=ds.data_ptr(), ld_add=ld, c_rows=rows0.data_ptr() if M0 else None)
+        a1 = dict(mode=K.EPI_MUL_ACC, aux0=mul.data_ptr(), out2=acc.data_ptr(), ld_aux=ld,
+                  c_rows=rows1.data_ptr() if M1 else None)
+        if how == "pair":
+            K.gemm_nt_pair(K.nt_problem(A0.data_ptr(), ld, Wa.data_ptr(), ld, ds.data_ptr(), ld, M0, H, H, **a0),
+                           K.nt_problem(A1.data_ptr(), ld, Wb.data_ptr(), ld, dg.data_ptr(), ld, M1, H, H, **a1))
+        else:
+            K.gemm_nt(A0.data_ptr(), ld, Wa.data_ptr(), ld, ds.data_ptr(), ld, M0, H, H, **a0)
+            K.gemm_nt(A1.data_ptr(), ld, Wb.data_ptr(), ld, dg.data_ptr(), ld, M1, H, H, **a1)
+        torch.cuda.synchronize()
+        out[how] = (ds.clone(), dg.clone(), acc.clone())
+    for x, y in zip(out["pair"], out["two"]):
+        assert torch.equal(x, y)
+    if M0:
+        assert float((out["pair"][0] - 1.0).abs().max()) > 0.0  # the first product did land
