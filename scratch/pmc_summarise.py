@@ -7,7 +7,7 @@ the launches of each C-ABI entry point (all template variants of its kernels tog
 import collections, csv, glob, json, re, sys
 
 # entry point -> kernels it launches; a call runs exactly one of the kernels before "|" (they count the calls)
-ENTRY = [("gemm_nt", ("gemm_nt_kernel", "gemm_nt_small_kernel", "|")), ("gemm_tn", ("gemm_tn_kernel", "|", "slab_reduce_kernel")),
+ENTRY = [("gemm_nt", ("gemm_nt_kernel", "gemm_nt_small_kernel", "gemm_nt_pair_kernel", "gemm_nt_small_pair_kernel", "|")), ("gemm_tn", ("gemm_tn_kernel", "|", "slab_reduce_kernel")),
          ("csr_gather_sum", ("csr_gather_sum_kernel",)), ("gru_gate_gather", ("gru_gate_gather_kernel",)),
          ("gru_bwd_gather", ("gru_bwd_gather_kernel",)), ("gru_bwd_pointwise", ("gru_bwd_pointwise_kernel",)),
          ("gru_iter0", ("gru_iter0_kernel",)), ("segment_mean", ("segment_mean_kernel",)),
