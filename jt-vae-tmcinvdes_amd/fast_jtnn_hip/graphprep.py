@@ -109,10 +109,67 @@ def check_range(col: np.ndarray, n_src: int, what: str) -> None:
                          % (what, n_src, int(col.min()), int(col.max())))
 
 
+class _UploadBatch:
+    """Index arrays of one prepared holder, shipped with one host-to-device copy per 4 MB chunk instead of
+    one small copy each (a tree holder with its schedules is ~100 arrays).  Arrays are laid out in pinned
+    staging memory as they are added and get their device views at once; ``flush`` issues the copies on the
+    current stream, ahead of every kernel that will read them."""
+
+    CHUNK = 1 << 20  # int32 elements
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.chunks = []  # [host, dev, used]
+
+    def add(self, a: np.ndarray) -> torch.Tensor:
+        n = int(a.size)
+        n4 = (n + 3) & ~3  # keep every array 16-byte aligned
+        if not self.chunks or self.chunks[-1][2] + n4 > self.chunks[-1][0].numel():
+            size = max(self.CHUNK, n4)
+            self.chunks.append([torch.empty(size, dtype=torch.int32, pin_memory=True),
+                                torch.empty(size, dtype=torch.int32, device=self.device), 0])
+        host, dev, used = self.chunks[-1]
+        host.numpy()[used:used + n] = a.reshape(-1)
+        self.chunks[-1][2] = used + n4
+        return dev[used:used + n]
+
+    def flush(self):
+        for host, dev, used in self.chunks:
+            if used:
+                dev[:used].copy_(host[:used], non_blocking=True)
+        self.chunks = []
+
+
+_ACTIVE_UPLOAD = None
+
+
+class packed_uploads:
+    """``with packed_uploads(device):`` - index arrays created inside go to the device in one copy."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def __enter__(self):
+        global _ACTIVE_UPLOAD
+        self.prev = _ACTIVE_UPLOAD
+        _ACTIVE_UPLOAD = _UploadBatch(self.device) if self.device.type == "cuda" else None
+        return self
+
+    def __exit__(self, *exc):
+        global _ACTIVE_UPLOAD
+        if _ACTIVE_UPLOAD is not None:
+            _ACTIVE_UPLOAD.flush()
+        _ACTIVE_UPLOAD = self.prev
+        return False
+
+
 def _dev_i32(a: np.ndarray, device) -> torch.Tensor:
     if a.size and int(a.max()) >= 2 ** 31:
         raise OverflowError("index exceeds int32")
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if _ACTIVE_UPLOAD is not None and _ACTIVE_UPLOAD.device == torch.device(device):
+        return _ACTIVE_UPLOAD.add(a)
+    return torch.from_numpy(a).to(device)
 
 
 def upload_csr(rowptr: np.ndarray, col: np.ndarray, device) -> DeviceCSR:
@@ -175,6 +232,11 @@ class GraphMPNPrep:
 
 
 def prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
+    with packed_uploads(device):
+        return _prepare_mpn(holder, device, n_tree)
+
+
+def _prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
     fatoms, fbonds, agraph, bgraph, scope = holder
     fa, fb = np.asarray(_to_np(fatoms), dtype=np.float32), np.asarray(_to_np(fbonds), dtype=np.float32)
     ag, bg = _to_np(agraph), _to_np(bgraph)
@@ -242,6 +304,11 @@ def _key_lists(keys: np.ndarray, n_keys: int, device):
 
 
 def prepare_tree(holder, device, vocab_size: int) -> TreePrep:
+    with packed_uploads(device):
+        return _prepare_tree(holder, device, vocab_size)
+
+
+def _prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     fnode, fmess, node_graph, mess_graph, scope = holder
     fn, fm = np.asarray(_to_np(fnode), dtype=np.int64), np.asarray(_to_np(fmess), dtype=np.int64)
     ng, mg = _to_np(node_graph), _to_np(mess_graph)
@@ -375,6 +442,11 @@ def _levels(rowptr, col, n, cap, start):
 
 
 def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False) -> TreeSchedule:
+    with packed_uploads(device):
+        return _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense)
+
+
+def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False) -> TreeSchedule:
     deg = np.diff(m_rp)
     tdeg = np.diff(mt_rp)
     if dense or T < 1:
@@ -406,6 +478,12 @@ def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False) 
 def build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], wid_m: np.ndarray, n_words: int,
                             device) -> BackwardSchedule:
     """seeds: message ids with a non-zero external gradient on the final h (None = all)."""
+    with packed_uploads(device):
+        return _build_backward_schedule(sched, seeds, wid_m, n_words, device)
+
+
+def _build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], wid_m: np.ndarray, n_words: int,
+                             device) -> BackwardSchedule:
     h = sched._host
     nm, T, sf = h["nm"], sched.T, h["sf"]
     m_rp, m_col, deg = h["m_rp"], h["m_col"], h["deg"]
