@@ -353,12 +353,13 @@ def _prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     )
 
 
-def tree_schedule(prep: TreePrep, T: int, dense: bool = False) -> TreeSchedule:
-    key = (T, bool(dense))
+def tree_schedule(prep: TreePrep, T: int, dense: bool = False, mode: str = None) -> TreeSchedule:
+    mode = mode or ("dense" if dense else "once")
+    key = (T, mode)
     if key not in prep.schedules:
         h = prep.host
         prep.schedules[key] = build_tree_schedule(h["m_rp"], h["m_col"], h["mt_rp"], h["mt_col"], prep.n_mess, T,
-                                                  h["device"], dense)
+                                                  h["device"], mode=mode)
     return prep.schedules[key]
 
 
@@ -419,10 +420,11 @@ class TreeSchedule:
     dense: bool
     sf: torch.Tensor  # int32 [NM] iteration from which a message no longer changes (capped at T)
     sel_final: torch.Tensor  # int32 [NM] slab that holds the final value: min(T, sf)
-    F: list  # RowList per iteration: messages to update (sf > t)
+    F: list  # RowList per iteration: messages to update (level: sf > t; once: sf == t + 1)
     U: list  # RowList per iteration t >= 1: messages whose U_r product is needed (changed at t-1, have readers)
     bwd: dict  # "all" / "roots" -> BackwardSchedule, built on first use
     _host: dict = None
+    mode: str = "level"  # "dense", "level" or "once" (see build_tree_schedule)
 
 
 def _levels(rowptr, col, n, cap, start):
@@ -441,12 +443,32 @@ def _levels(rowptr, col, n, cap, start):
     return lev
 
 
-def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False) -> TreeSchedule:
+def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False, mode: str = None) -> TreeSchedule:
+    """Row lists of the T GraphGRU iterations.
+
+    mode "dense": every message in every iteration, the reference's schedule (jtnn_enc.py:107-128).
+    mode "level": iteration t updates the messages that can still change (stable_from > t).
+    mode "once":  iteration t updates only the messages that BECOME stable in it (stable_from == t + 1).
+        A message's final value is f(final values of the messages it reads); the values it takes before
+        its inputs have settled are read by nobody once the recurrence has run to its fixed point, so when
+        every message settles within T iterations (tree depth <= T) computing each message once, level by
+        level, gives the reference's result.  Batches with a deeper tree fall back to "level", where the
+        truncated recurrence is followed iteration by iteration.
+    """
+    mode = mode or ("dense" if dense else "once")
+    if mode not in ("dense", "level", "once"):
+        raise ValueError("unknown schedule mode %r" % (mode,))
+    if mode == "once":
+        deep = T < 1 or (nm > 0 and int(K.prep_stable_from(m_rp, m_col, T + 1).max()) > T)
+        if deep:
+            mode = "level"
     with packed_uploads(device):
-        return _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense)
+        return _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode)
 
 
-def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False) -> TreeSchedule:
+def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode) -> TreeSchedule:
+    dense = mode == "dense"
+    once = mode == "once"
     deg = np.diff(m_rp)
     tdeg = np.diff(mt_rp)
     if dense or T < 1:
@@ -459,20 +481,22 @@ def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False)
         if dense or t == 0:
             F.append(RowList(None, nm, total_nnz))
         else:
-            r = np.flatnonzero(sf > t)
+            r = np.flatnonzero(sf == t + 1) if once else np.flatnonzero(sf > t)
             F.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size), int(deg[r].sum())))
         if t == 0:
             U.append(RowList(None, 0))
         elif dense:
             U.append(RowList(None, nm))
         else:
-            r = np.flatnonzero((sf >= t) & (tdeg > 0))  # changed in iteration t-1 and somebody reads it
+            # messages whose U_r product is read in this iteration and not yet available: those that took
+            # their current value in iteration t-1 and have readers
+            r = np.flatnonzero(((sf == t) if once else (sf >= t)) & (tdeg > 0))
             U.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size)))
     host = dict(m_rp=np.asarray(m_rp, dtype=np.int64), m_col=np.asarray(m_col, dtype=np.int64),
                 mt_rp=np.asarray(mt_rp, dtype=np.int64), mt_col=np.asarray(mt_col, dtype=np.int64), sf=sf, nm=nm,
                 deg=deg.astype(np.int64), tdeg=tdeg.astype(np.int64))
     return TreeSchedule(T=T, dense=dense, sf=_dev_i32(sf, device), sel_final=_dev_i32(np.minimum(sf, T), device),
-                        F=F, U=U, bwd={}, _host=host)
+                        F=F, U=U, bwd={}, _host=host, mode=mode)
 
 
 def build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], wid_m: np.ndarray, n_words: int,

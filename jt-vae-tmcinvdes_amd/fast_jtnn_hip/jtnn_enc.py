@@ -32,7 +32,10 @@ from . import graphprep
 from .mpn import as_row_buffer, dense_view, pack_weights
 
 
-SCHEDULE = "level"  # "level": update only messages that can still change; "dense": the reference's schedule
+# "once": every message computed once, in the iteration in which it settles (falls back to "level" for batches
+# with a tree deeper than the iteration count); "level": update the messages that can still change;
+# "dense": the reference's schedule, all messages in all iterations
+SCHEDULE = "once"
 
 
 class _TreeGRU:
@@ -160,7 +163,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         # grad mode is off inside forward(): the caller's mode comes in as an argument
         train = grad_on and any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)  # an unused output (messages in encode_latent) costs nothing
-        sched = graphprep.tree_schedule(P, depth, dense=(SCHEDULE == "dense"))
+        sched = graphprep.tree_schedule(P, depth, mode=SCHEDULE)
 
         # embedding rows of the words that occur in the batch            (jtnn_enc.py:27-28)
         E_p = as_row_buffer(E, H, ld)
@@ -331,8 +334,7 @@ class GraphGRU(nn.Module):
             K.gemm_nt(x_p.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NM, H, H,
                       bias=self.W_h.bias.data_ptr())
             trp, tcol = graphprep.transpose_csr(rp, col, NM)
-            sched = graphprep.build_tree_schedule(rp, col, trp, tcol, NM, self.depth, dev,
-                                                  dense=(SCHEDULE == "dense"))
+            sched = graphprep.build_tree_schedule(rp, col, trp, tcol, NM, self.depth, dev, mode=SCHEDULE)
             out, _ = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur_p,
                                       self.U_r.bias.detach(), Whh, False)
         return dense_view(out, H)

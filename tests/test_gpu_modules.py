@@ -273,35 +273,82 @@ def test_out_of_range_index_is_rejected_on_the_host():
 
 @pytest.mark.parametrize("with_messages", [True, False])
 def test_level_schedule_is_bitwise_the_dense_schedule(with_messages):
-    """Updating only the messages that can still change gives bit-identical outputs and gradients to
-    the reference's schedule (all messages, all 20 iterations)."""
+    """Updating only the messages that can still change ("level"), or each message only in the iteration
+    in which it settles ("once"), gives bit-identical outputs to the reference's schedule (all messages,
+    all 20 iterations) when all three go through the same GEMM kernel."""
     import fast_jtnn_hip.jtnn_enc as enc
 
     g = Golden(CASES[2])
-    results = []
-    for mode in ("dense", "level"):
+    results = {}
+    for mode in ("dense", "level", "once"):
         enc.SCHEDULE = mode
         try:
             m = make_hip_model(g, "cuda")
             tv, ms = m.jtnn(*g.jtenc_holder())
             loss = (tv * tv).sum() + ((ms * 0.3).sin().sum() if with_messages else 0.0)
             loss.backward()
-            results.append((tv.detach().clone(), ms.detach().clone(),
-                            {n: p.grad.clone() for n, p in m.jtnn.named_parameters()}))
+            results[mode] = (tv.detach().clone(), ms.detach().clone(),
+                             {n: p.grad.clone() for n, p in m.jtnn.named_parameters()})
         finally:
-            enc.SCHEDULE = "level"
-    (tv_d, ms_d, g_d), (tv_l, ms_l, g_l) = results
-    assert torch.equal(tv_d, tv_l) and torch.equal(ms_d, ms_l)
-    for n in g_d:
-        # weight gradients sum the same terms, but the level schedule leaves out exact zeros and
-        # groups the rest differently: equal to rounding, not bitwise
-        assert rel_err(g_l[n].cpu().numpy(), g_d[n].cpu().numpy()) < 2e-6, n
+            enc.SCHEDULE = "once"
+    tv_d, ms_d, g_d = results["dense"]
+    for mode in ("level", "once"):
+        tv_l, ms_l, g_l = results[mode]
+        assert torch.equal(tv_d, tv_l) and torch.equal(ms_d, ms_l), mode
+        for n in g_d:
+            # weight gradients sum the same terms, but the sparse schedules leave out exact zeros and
+            # group the rest differently: equal to rounding, not bitwise
+            assert rel_err(g_l[n].cpu().numpy(), g_d[n].cpu().numpy()) < 2e-6, (mode, n)
     with torch.no_grad():
         tv_i, ms_i = make_hip_model(g, "cuda").jtnn(*g.jtenc_holder())
-    assert torch.equal(tv_i, tv_l) and torch.equal(ms_i, ms_l)
+    assert torch.equal(tv_i, tv_d) and torch.equal(ms_i, ms_d)
 
 
-def test_level_schedule_at_batch_scale_equals_dense_to_rounding():
+def test_tree_deeper_than_the_iteration_count_follows_the_truncated_recurrence():
+    """With a tree deeper than depthT the reference's result is a truncated propagation, not the fixed
+    point: the compute-once schedule must notice and fall back, and the result must still be the dense
+    one (and the CPU oracle's)."""
+    import fast_jtnn_hip.jtnn_enc as enc
+    from fast_jtnn_hip import JTNNEncoder, graphprep, synthetic, tensorize as T
+    from oracle.ref_encoder import OracleJTNNEncoder
+
+    rs = np.random.RandomState(0)
+    mol = synthetic.make_mol(rs, 9.0, 1.0, 5, 12)
+    nodes = [synthetic.TreeNode(i, int(rs.randint(0, 7))) for i in range(9)]  # a chain of 9 clusters
+    for a, b in zip(nodes[:-1], nodes[1:]):
+        a.neighbors.append(b); b.neighbors.append(a)
+    trees = [synthetic.Tree(nodes, mol)]
+    synthetic.set_batch_nodeID(trees)
+    jt, _ = T.jtenc_tensorize(trees)
+    H, depth = 64, 3
+    outs = {}
+    for mode in ("dense", "once"):
+        enc.SCHEDULE = mode
+        try:
+            m = JTNNEncoder(H, depth, torch.nn.Embedding(7, H)).cuda()
+            synthetic.fill_params(list(m.named_parameters()), 4, 0.1)
+            tv, ms = m(*jt)
+            (tv.sum() + (ms * ms).sum()).backward()
+            outs[mode] = (tv.detach().cpu().numpy(), ms.detach().cpu().numpy(),
+                          {n: p.grad.cpu().numpy() for n, p in m.named_parameters()})
+        finally:
+            enc.SCHEDULE = "once"
+    rp, col = graphprep.padded_to_csr(jt[3].numpy(), jt[3].shape[0])
+    trp, tcol = graphprep.transpose_csr(rp, col, jt[3].shape[0])
+    sched = graphprep.build_tree_schedule(rp, col, trp, tcol, jt[3].shape[0], depth, "cpu", mode="once")
+    assert sched.mode == "level"  # fell back: the chain is deeper than 3 iterations
+    assert np.array_equal(outs["once"][0], outs["dense"][0]) and np.array_equal(outs["once"][1], outs["dense"][1])
+    ora = OracleJTNNEncoder(H, depth, torch.nn.Embedding(7, H))
+    synthetic.fill_params(list(ora.named_parameters()), 4, 0.1)
+    tvo, mso = ora(*jt)
+    assert rel_err(outs["once"][0], tvo.detach().numpy()) < RTOL
+    assert rel_err(outs["once"][1], mso.detach().numpy()) < RTOL
+    (tvo.sum() + (mso * mso).sum()).backward()
+    for n, q in ora.named_parameters():
+        assert fro_err(outs["once"][2][n], q.grad.numpy()) < RTOL, n
+
+
+def test_sparse_schedules_at_batch_scale_equal_dense_to_rounding():
     """At batch scale the row count of a launch picks the GEMM kernel (tiled or whole-K-in-LDS), whose
     summation orders differ, so the active-row schedule and the dense one agree to fp32 rounding rather
     than bit for bit."""
@@ -315,7 +362,7 @@ def test_level_schedule_at_batch_scale_equals_dense_to_rounding():
     trees = synthetic.make_batch(5, 160, vocab_size=385)
     jt, _ = T.jtenc_tensorize(trees)
     out = {}
-    for mode in ("dense", "level"):
+    for mode in ("dense", "level", "once"):
         enc.SCHEDULE = mode
         try:
             m = make_hip_model(g, "cuda")
@@ -324,12 +371,13 @@ def test_level_schedule_at_batch_scale_equals_dense_to_rounding():
             out[mode] = (tv.detach().cpu().numpy(), ms.detach().cpu().numpy(),
                          {n: p.grad.cpu().numpy() for n, p in m.jtnn.named_parameters()})
         finally:
-            enc.SCHEDULE = "level"
+            enc.SCHEDULE = "once"
     assert out["dense"][1].shape[0] > 4000  # enough messages for the tiled kernel in the dense run
-    assert rel_err(out["level"][0], out["dense"][0]) < 2e-6
-    assert rel_err(out["level"][1], out["dense"][1]) < 2e-6
-    for n in out["dense"][2]:
-        assert fro_err(out["level"][2][n], out["dense"][2][n]) < 1e-5, n
+    for mode in ("level", "once"):
+        assert rel_err(out[mode][0], out["dense"][0]) < 2e-6, mode
+        assert rel_err(out[mode][1], out["dense"][1]) < 2e-6, mode
+        for n in out["dense"][2]:
+            assert fro_err(out[mode][2][n], out["dense"][2][n]) < 1e-5, (mode, n)
 
 
 def test_training_scale_step_with_candidates_properties():

@@ -84,3 +84,36 @@ def test_native_prep_matches_numpy_statements():
         G.padded_to_csr(np.array([[1, 9]], dtype=np.int64), 9)
     with pytest.raises(IndexError):
         G.padded_to_csr(np.array([[-1, 0]], dtype=np.int64), 9)
+
+
+def test_compute_once_schedule_covers_every_message_exactly_once():
+    """Mode "once": apart from iteration 0 (which evaluates every message on empty inputs), a message is
+    updated in exactly one iteration, the one in which it settles, and reads only settled messages."""
+    from fast_jtnn_hip import synthetic, tensorize as T
+    trees = synthetic.make_batch(3, 40, vocab_size=30)
+    jt, _ = T.jtenc_tensorize(trees)
+    mg = jt[3].numpy()
+    nm = mg.shape[0]
+    rp, col = G.padded_to_csr(mg, nm)
+    trp, tcol = G.transpose_csr(rp, col, nm)
+    Tn = 20
+    once = G.build_tree_schedule(rp, col, trp, tcol, nm, Tn, "cpu", mode="once")
+    level = G.build_tree_schedule(rp, col, trp, tcol, nm, Tn, "cpu", mode="level")
+    assert once.mode == "once"
+    sf = once.sf.numpy()
+    assert np.array_equal(sf, level.sf.numpy())
+    seen = np.zeros(nm, dtype=np.int64)
+    seen[sf == 1] += 1  # settled by iteration 0
+    for t in range(1, Tn):
+        rows = once.F[t].rows.numpy() if once.F[t].rows is not None else np.zeros(0, np.int64)
+        assert once.F[t].n == rows.size and np.all(sf[rows] == t + 1)
+        seen[rows] += 1
+        for m in rows[:50]:
+            assert np.all(sf[col[rp[m]:rp[m + 1]]] <= t)  # inputs have settled
+        urows = once.U[t].rows.numpy() if once.U[t].rows is not None else np.zeros(0, np.int64)
+        assert np.all(sf[urows] == t)
+        assert once.F[t].n <= level.F[t].n
+    assert np.all(seen == 1)
+    # a batch deeper than the iteration count falls back to the iteration-by-iteration form
+    shallow_T = int(sf.max()) - 1
+    assert G.build_tree_schedule(rp, col, trp, tcol, nm, shallow_T, "cpu", mode="once").mode == "level"
