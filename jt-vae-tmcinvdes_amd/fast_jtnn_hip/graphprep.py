@@ -554,7 +554,9 @@ def _build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], w
         full = r.size == nm
         Jl.append(RowList(None if full else (_dev_i32(r, device) if r.size else None), int(r.size),
                           int(tdeg[r].sum())))
-    # weight-gradient contraction lists
+    # weight-gradient contraction lists; saved-state rows are addressed as slab * slab_rows + message, and the
+    # compute-once schedule keeps a single slab
+    slab_rows = 0 if sched.mode == "once" else nm
     zx, zy, ux, uy, keys = [], [], [], [], []
     for t in range(T):
         r = sets[t]
@@ -565,11 +567,11 @@ def _build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], w
             tau = np.minimum(t, sf[r] - 1)
             ok = tau >= 1  # iteration 0 has s == g == 0: no contribution
             zx.append(offE[t] + np.flatnonzero(ok))
-            zy.append(tau[ok] * nm + r[ok])
+            zy.append(tau[ok] * slab_rows + r[ok])
             j = sets[t - 1]
             if j.size:
                 ux.append(offJ[t] + np.arange(j.size))
-                uy.append(np.minimum(t, sf[j]) * nm + j)
+                uy.append(np.minimum(t, sf[j]) * slab_rows + j)
     cat = lambda l: np.concatenate(l) if l else np.zeros(0, dtype=np.int64)  # noqa: E731
     zx, zy, ux, uy, keys = cat(zx), cat(zy), cat(ux), cat(uy), cat(keys)
     if (T + 1) * nm >= 2 ** 31:

@@ -51,14 +51,20 @@ class _TreeGRU:
         wid_p = wid.data_ptr()
         if T == 0:
             return K.rows(NM, ld, dev, zero=True), {}
+        # With the compute-once schedule a message has ONE saved state, that of the iteration in which it
+        # settled: all "slabs" alias one [NM, ld] buffer (slab stride 0) and later iterations overwrite the
+        # provisional rows iteration 0 left there.  The other schedules keep one slab per iteration.
+        compact = sched.mode == "once"
         if train:
-            hs = torch.empty((T + 1, NM, ld), dtype=torch.float32, device=dev)
-            zs, ps, ss, gs, ts, us = (torch.empty((T, NM, ld), dtype=torch.float32, device=dev) for _ in range(6))
-            stride = NM * ld
+            n_slab = 1 if compact else T
+            hs = torch.empty((1 if compact else T + 1, NM, ld), dtype=torch.float32, device=dev)
+            zs, ps, ss, gs, ts, us = (torch.empty((n_slab, NM, ld), dtype=torch.float32, device=dev)
+                                      for _ in range(6))
+            stride = 0 if compact else NM * ld
             sf_p = sched.sf.data_ptr()
-            st = dict(hs=hs, zs=zs, ps=ps, ss=ss, gs=gs, ts=ts, us=us)
-            K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, zs[0].data_ptr(), ps[0].data_ptr(), hs[1].data_ptr(),
-                        NM, H, ld, pad_row)
+            st = dict(hs=hs, zs=zs, ps=ps, ss=ss, gs=gs, ts=ts, us=us, stride=stride)
+            K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, zs[0].data_ptr(), ps[0].data_ptr(),
+                        hs[0 if compact else 1].data_ptr(), NM, H, ld, pad_row)
         else:
             # inference: one buffer each, updated in place (frozen rows simply keep their value)
             hs = torch.empty((1, NM, ld), dtype=torch.float32, device=dev)
@@ -69,9 +75,10 @@ class _TreeGRU:
             F, U = sched.F[t], sched.U[t]
             if F.n == 0:
                 break  # every message has reached its fixed point
-            i = t if train else 0
-            h_in = hs[t] if train else hs[0]
-            h_out = hs[t + 1] if train else hs[0]
+            slabbed = train and not compact
+            i = t if slabbed else 0
+            h_in = hs[t] if slabbed else hs[0]
+            h_out = hs[t + 1] if slabbed else hs[0]
             # Uh = U_r h + b for the messages that changed in the last iteration and are read by someone
             K.gemm_nt(h_in.data_ptr(), ld, Ur.data_ptr(), ld, us[i].data_ptr(), ld, U.n, H, H, bias=bu.data_ptr(),
                       a_rows=U.ptr(), c_rows=U.ptr())
@@ -86,7 +93,7 @@ class _TreeGRU:
                       add=Ph.data_ptr(), ld_add=ld, add_idx=wid_p, mode=K.EPI_GRU_BLEND,
                       aux0=zs[i].data_ptr(), aux1=ss[i].data_ptr(), out2=h_out.data_ptr(), ld_aux=ld,
                       a_rows=F.ptr(), c_rows=F.ptr(), zero_row=pad_row)
-        if train:
+        if train and not compact:
             h = K.rows(NM, ld, dev)
             K.select_slab_rows(h.data_ptr(), hs.data_ptr(), stride, sched.sel_final.data_ptr(), NM, H, ld)
         else:
@@ -99,7 +106,7 @@ class _TreeGRU:
         Returns compact (dz [nE], dp [nE], du [nJ]) and A_r [NM] for the weight / table gradients."""
         T = sched.T
         hs, zs, ps, ss, gs, ts, us = (st[k] for k in ("hs", "zs", "ps", "ss", "gs", "ts", "us"))
-        stride = NM * ld
+        stride = st["stride"]
         sf_p = sched.sf.data_ptr()
         act_p = None if bs.active is None else bs.active.data_ptr()
         dz = K.rows(max(bs.nE, 1), ld, dev)
