@@ -30,7 +30,10 @@ int main(int argc, char** argv) {
     return 0;
   }
 #else
-  size_t nst = (size_t)blocks * 4 * JTVAE_TRACE_SLOTS;
+  // the library may pick a tiling with more blocks than the 128 x 96 one counted above (128 x 32 for mid-size
+  // launches): size the stamp buffer for the finest tiling any kernel uses
+  const int blocks_max = ((M + 31) / 32) * 15;
+  size_t nst = (size_t)blocks_max * 4 * JTVAE_TRACE_SLOTS;
   unsigned long long* T;
   CK(hipMalloc(&T, nst * 8)); CK(hipMemset(T, 0, nst * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
