@@ -19,8 +19,11 @@ What is computed differently from the reference's op sequence (same mathematics)
   blend are epilogues of the two remaining GEMMs.
 * only the root node of each tree needs ``outputNN`` (jtnn_enc.py:36-41 keeps
   ``node_vecs[st]`` only), so the output stage runs on B rows.
-* backward is explicit; every per-iteration tensor it needs is kept in HBM
-  (7 row buffers per iteration) instead of autograd's [NM, K, H] saves.
+* a message is computed once, in the iteration in which all messages it reads have settled:
+  the 20 synchronous iterations of the reference recompute every message until then, and
+  nothing downstream ever reads those provisional values (``graphprep.build_tree_schedule``).
+* backward is explicit; the 7 row buffers it needs per message are kept in HBM instead of
+  autograd's [NM, K, H] saves per iteration.
 """
 from __future__ import annotations
 
@@ -39,10 +42,11 @@ SCHEDULE = "once"
 
 
 class _TreeGRU:
-    """Forward/backward body of GraphGRU on padded row buffers, driven by an active-row schedule.
+    """Forward/backward body of GraphGRU on padded row buffers, driven by the row lists of a schedule.
 
-    Tables Pz, Pr, Ph are [n_words, ld]; wid maps a message to its table row.  Per-iteration state
-    (training) lives in slabs [T(+1), NM, ld] of which only the rows of the schedule are written.
+    Tables Pz, Pr, Ph are [n_words, ld]; wid maps a message to its table row.  Saved state (training)
+    is one [NM, ld] buffer per quantity under the compute-once schedule, slabs [T(+1), NM, ld] of which
+    only the rows of the schedule are written under the other two.
     """
 
     @staticmethod

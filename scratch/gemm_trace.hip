@@ -9,7 +9,7 @@
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 85181;
   const char* out = argc > 2 ? argv[2] : "trace.bin";
-  const int N = 450, K = 450, ld = 452;
+  const int N = argc > 3 ? atoi(argv[3]) : 450, K = N, ld = (N + 3) & ~3;
   std::vector<float> hA((size_t)M * ld), hW((size_t)N * ld);
   for (size_t i = 0; i < hA.size(); ++i) hA[i] = ((i * 2654435761u) % 1000) / 500.f - 1.f;
   for (size_t i = 0; i < hW.size(); ++i) hW[i] = ((i * 40503u) % 1000) / 500.f - 1.f;
@@ -17,7 +17,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&C, (size_t)M * ld * 4));
   CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
-  int blocks = ((M + 127) / 128) * 5;
+  int blocks = ((M + 127) / 128) * ((N + 95) / 96);
 #ifndef JTVAE_GEMM_TRACE
   {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
 #else
   // the library may pick a tiling with more blocks than the 128 x 96 one counted above (128 x 32 for mid-size
   // launches): size the stamp buffer for the finest tiling any kernel uses
-  const int blocks_max = ((M + 31) / 32) * 15;
+  const int blocks_max = ((M + 31) / 32) * ((N + 31) / 32);
   size_t nst = (size_t)blocks_max * 4 * JTVAE_TRACE_SLOTS;
   unsigned long long* T;
   CK(hipMalloc(&T, nst * 8)); CK(hipMemset(T, 0, nst * 8));
