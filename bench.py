@@ -46,20 +46,24 @@ def pmc_traffic():
         return {}
 
 
-def build_problem(seed, batch, vocab, device):
+def build_problem(seed, batch, vocab, device, with_cands=False):
     from fast_jtnn_hip import JTNNVAE, synthetic
     from fast_jtnn_hip import tensorize as T
 
-    trees = synthetic.make_batch(seed, batch, vocab_size=vocab, mean_atoms=40.0)
-    jt, _ = T.jtenc_tensorize(trees)
+    trees = synthetic.make_batch(seed, batch, vocab_size=vocab, mean_atoms=40.0, with_cands=with_cands)
+    jt, mess_dict = T.jtenc_tensorize(trees)
     mp = T.mpn_tensorize([t.mol for t in trees])
     model = JTNNVAE(synthetic.FakeVocab(vocab), 450, 56, 20, 3)
     synthetic.fill_params(list(model.named_parameters()), seed=0, bias_scale=0.0)  # trainer init rule
     model = model.to(device)
-    # only the encoder path is stepped: candidate scorer and assembly head take no part
-    for n, p in model.named_parameters():
-        if n.startswith("jtmpn.") or n.startswith("A_assm."):
-            p.requires_grad_(False)
+    if with_cands:
+        cands, batch_idx = synthetic.collect_candidates(trees)
+        model.bench_assm = (trees, (T.jtmpn_tensorize(cands, mess_dict), torch.from_numpy(batch_idx)))
+    else:
+        # only the encoder path is stepped: candidate scorer and assembly head take no part
+        for n, p in model.named_parameters():
+            if n.startswith("jtmpn.") or n.startswith("A_assm."):
+                p.requires_grad_(False)
     stats = dict(atoms=int(mp[0].shape[0]), directed_bonds=int(mp[1].shape[0]) - 1,
                  tree_nodes=int(jt[0].shape[0]), tree_messages=int(jt[1].shape[0]) - 1,
                  nnz_bgraph=int((mp[3] != 0).sum()), nnz_agraph=int((mp[2] != 0).sum()),
@@ -108,9 +112,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="print a per-shape GEMM table to stderr")
-    ap.add_argument("--mode", default="train", choices=("train", "encode"),
+    ap.add_argument("--mode", default="train", choices=("train", "encode", "train_assm"),
                     help="train: forward + backward (the headline metric); encode: no-grad bulk encoding to "
-                         "[B, 900] vectors (latent generation), reported under its own metric name")
+                         "[B, 900] vectors (latent generation), reported under its own metric name; train_assm: encoders + candidate-graph JTMPN + "
+                         "assembly loss + KL, forward + backward (a training step without the tree decoder)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the tree encoder and the graph encoder on two overlapping streams instead of back to "
                          "back on one (faster step; per-kernel durations then include co-running kernels)")
@@ -134,7 +139,8 @@ def main():
     device = torch.device("cuda", dev_index)
     parallel.init_process_group(args.backend, device_index=dev_index)
 
-    model, jt, mp, stats = build_problem(seed=1234 + rank, batch=args.batch, vocab=args.vocab, device=device)
+    model, jt, mp, stats = build_problem(seed=1234 + rank, batch=args.batch, vocab=args.vocab, device=device,
+                                        with_cands=args.mode == "train_assm")
     model.overlap_streams = bool(args.overlap)
     bucket = parallel.FlatGradBucket([p for p in model.parameters() if p.requires_grad])
 
@@ -148,7 +154,21 @@ def main():
         with torch.no_grad():
             model.encode_vectors(jt, mp)
 
-    step = train_step if args.mode == "train" else encode_step
+    def train_assm_step():  # jtnn_vae.py:85-103 without the decoder terms
+        bucket.zero()
+        trees, assm_holder = model.bench_assm
+        tree_vecs, tree_mess, mol_vecs = model.encode(jt, mp)
+        _, tree_kl = model.rsample(tree_vecs, model.T_mean, model.T_var, eps[0])
+        z_mol, mol_kl = model.rsample(mol_vecs, model.G_mean, model.G_var, eps[1])
+        assm_loss, _ = model.assm(trees, assm_holder, z_mol, tree_mess)
+        (assm_loss + 0.005 * (tree_kl + mol_kl)).backward()
+        bucket.all_reduce_mean()
+
+    if args.mode == "train_assm":
+        g = torch.Generator(device="cpu").manual_seed(7)
+        eps = [torch.randn((args.batch, 28), generator=g).to(device) for _ in range(2)]
+        stats["candidates"] = int(model.bench_assm[1][1].shape[0])
+    step = {"train": train_step, "encode": encode_step, "train_assm": train_assm_step}[args.mode]
 
     def barrier():
         if world > 1:
@@ -171,16 +191,19 @@ def main():
     value = args.batch * world * args.steps / elapsed
 
     out = {
-        "metric": "encoder fwd+bwd molecules/sec" if args.mode == "train" else "encoder no-grad encode molecules/sec",
+        "metric": {"train": "encoder fwd+bwd molecules/sec", "encode": "encoder no-grad encode molecules/sec",
+                   "train_assm": "encoder + candidate scorer + assembly loss fwd+bwd molecules/sec"}[args.mode],
         "value": round(value, 1), "unit": "molecules/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "synthetic batch of %d molecular graphs per GPU (~40 atoms, <=6 neighbours): "
                                "MPN depthG=3 + JTNNEncoder/GraphGRU depthT=20, hidden 450, latent 56, "
-                               "%s%s" % (args.batch, "forward + backward" if args.mode == "train" else "forward only (no grad)",
+                               "%s%s" % (args.batch, {"train": "forward + backward", "encode": "forward only (no grad)",
+                                                "train_assm": "with JTMPN on the candidate graphs and the assembly "
+                                                              "loss, forward + backward"}[args.mode],
                                                " + flat-bucket %s gradient all-reduce" %
                                                          ("RCCL" if args.backend == "nccl" else args.backend)
-                                                         if world > 1 and args.mode == "train" else ""),
+                                                         if world > 1 and args.mode != "encode" else ""),
                    "molecules_per_gpu": args.batch, "global_batch": args.batch * world, "vocab": args.vocab,
                    "parallelism": "dp%d" % world, "streams": 2 if args.overlap else 1, "grad_bucket_bytes": bucket.nbytes(), **stats},
     }

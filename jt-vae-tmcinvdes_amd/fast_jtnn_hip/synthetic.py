@@ -43,7 +43,7 @@ class MolGraph:
         return int(self.atom_feats.shape[0])
 
 
-@dataclass
+@dataclass(eq=False)  # candidates compare by identity, like the distinct SMILES strings they stand in for
 class CandGraph:
     """One attachment candidate as the JTMPN tensorizer sees it.
 
