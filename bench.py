@@ -103,12 +103,16 @@ def cpu_baseline(seed, vocab, sample_b=32, reps=3):
 
 
 def main():
+    if os.environ.get("JTVAE_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["JTVAE_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="molecules per GPU")
     ap.add_argument("--vocab", type=int, default=385)
+    ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic batch (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="print a per-shape GEMM table to stderr")
@@ -139,7 +143,7 @@ def main():
     device = torch.device("cuda", dev_index)
     parallel.init_process_group(args.backend, device_index=dev_index)
 
-    model, jt, mp, stats = build_problem(seed=1234 + rank, batch=args.batch, vocab=args.vocab, device=device,
+    model, jt, mp, stats = build_problem(seed=args.seed + rank, batch=args.batch, vocab=args.vocab, device=device,
                                         with_cands=args.mode == "train_assm")
     model.overlap_streams = bool(args.overlap)
     bucket = parallel.FlatGradBucket([p for p in model.parameters() if p.requires_grad])

@@ -214,10 +214,15 @@ class KernelTimer:
         return out
 
 
+_SYNC_EACH = bool(os.environ.get("JTVAE_SYNC_EACH"))  # debugging aid: a stall or fault then names its launch
+
+
 def _run(name, fn, args, nbytes=0, flops=0, tag=""):
     t = KernelTimer.active
     if t is None:
         check(fn(*args), name)
+        if _SYNC_EACH:
+            torch.cuda.current_stream().synchronize()
         return
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)

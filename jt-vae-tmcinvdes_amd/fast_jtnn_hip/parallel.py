@@ -95,6 +95,11 @@ class FlatGradBucket:
 
     def all_reduce_mean(self) -> None:
         if dist.is_initialized() and dist.get_world_size() > 1:
+            if self.flat.is_cuda:
+                # The gradients are final only when the backward kernels have run; handing the collective a
+                # buffer with that work still queued stalled a host-staged backend (gloo, two ranks on one GPU).
+                # Waiting here costs one launch latency per step - nothing follows backward that could overlap.
+                torch.cuda.current_stream(self.flat.device).synchronize()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
 
