@@ -454,3 +454,28 @@ def test_assembly_loss_matches_reference_loop():
     assert abs(loss.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item())
     assert int(hits.item()) == ref_hits
     assert rel_err(sc.grad.cpu().numpy(), 0.5 * ref_scores.grad.numpy()) < 1e-5
+
+
+def test_standalone_graph_gru_matches_oracle():
+    """GraphGRU.forward(h, x, mess_graph) with explicit per-message inputs, the reference's stand-alone
+    signature (fast_jtnn/jtnn_enc.py:107-128): inference only, against the CPU oracle."""
+    from fast_jtnn_hip import GraphGRU, synthetic, tensorize as T
+    from oracle.ref_encoder import OracleGraphGRU
+
+    trees = synthetic.make_batch(8, 12, vocab_size=20)
+    jt, _ = T.jtenc_tensorize(trees)
+    mess_graph = jt[3]
+    NM, H, depth = mess_graph.shape[0], 450, 20
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(rs.standard_normal((NM, H)).astype(np.float32) * 0.3)
+    x[0] = 0  # the padding message carries no input, as in JTNNEncoder (fmess[0] = 0 -> masked anyway)
+    hip, ora = GraphGRU(H, H, depth).cuda(), OracleGraphGRU(H, H, depth)
+    synthetic.fill_params(list(hip.named_parameters()), 9, 0.1)
+    synthetic.fill_params(list(ora.named_parameters()), 9, 0.1)
+    with torch.no_grad():
+        got = hip(torch.zeros(NM, H), x, mess_graph)
+        want = ora(torch.zeros(NM, H), x, mess_graph)
+    assert rel_err(got.cpu().numpy(), want.numpy()) < RTOL
+    assert float(got[0].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        hip(torch.zeros(NM, H), x, mess_graph)  # gradients enabled: train through JTNNEncoder instead
