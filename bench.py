@@ -97,7 +97,16 @@ def cpu_baseline(seed, vocab, sample_b=32, reps=3):
         t0 = time.perf_counter()
         step()
         best = min(best, time.perf_counter() - t0)
-    return {"value": sample_b / best, "unit": "molecules/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": sample_b / best, "unit": "molecules/s", "cores": cores, "kind": "port", "cpu": cpu_model,
             "sample": "CPU oracle (reference op sequence, torch CPU fp32), fwd+bwd on %d molecules of the same "
                       "generator, best of %d after 1 warm-up" % (sample_b, reps)}
 
