@@ -71,7 +71,7 @@ def build_problem(seed, batch, vocab, device, with_cands=False):
     return model, jt, mp, stats
 
 
-def cpu_baseline(seed, vocab, sample_b=32, reps=3):
+def cpu_baseline(seed, vocab, sample_b=256, reps=2):
     """The CPU oracle (the reference's op sequence in PyTorch CPU ops) on a bounded sample of the
     same workload, timed on this host's cores."""
     from fast_jtnn_hip import synthetic
