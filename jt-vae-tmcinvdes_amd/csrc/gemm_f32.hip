@@ -870,6 +870,7 @@ int jtvae_gemm_nt_pair(const jtvae_gemm_nt_problem_t* p0, const jtvae_gemm_nt_pr
   if (rc != 0) return rc;
   rc = nt_setup(p1->A, p1->lda, p1->W, p1->ldw, p1->C, p1->ldc, p1->M, p1->N, p1->K, p1->epi, b, vec_b);
   if (rc != 0) return rc;
+  if (p0->M == 0 && p1->M == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   // one launch for the combination the tree GRU's backward pass issues (plain + multiply-accumulate
   // epilogue) when both products are small or mid-size; anything else runs as two launches

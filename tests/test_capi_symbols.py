@@ -42,6 +42,20 @@ def test_argument_checks_happen_before_launch():
     assert b"NULL" in lib.jtvae_error_string(-1)
     # zero-sized problems are accepted without touching the device
     assert lib.jtvae_segment_mean(None, None, None, 0, 450, 452, None) == 0
+    assert lib.jtvae_segment_ce(None, None, None, 0, None, None, None, None) == 0
+    assert lib.jtvae_segment_ce(None, None, None, 3, None, None, None, None) == -1
+    assert lib.jtvae_pack_batch(None, 0, None) == 0
+    assert lib.jtvae_pack_batch(None, 3, None) == -1
+    assert lib.jtvae_pack_batch(None, K.PACK_MAX + 1, None) == -2
+    bad = (K.PackItem * 1)(K.PackItem(src=16, dst=16, ld_src=4, ld_dst=4, rows=3, cols=8, transpose=0))  # cols > ld
+    assert lib.jtvae_pack_batch(bad, 1, None) == -2
+    assert lib.jtvae_gemm_nt_pair(None, None, None) == -1
+    p_ok = K.nt_problem(16, 452, 16, 452, 16, 452, 0, 450, 450)   # M = 0: nothing to do
+    p_bad = K.nt_problem(16, 452, 16, 452, 16, 452, 8, 450, 450, mode=K.EPI_MUL_ACC)  # epilogue operands missing
+    assert lib.jtvae_gemm_nt_pair(ctypes.byref(p_ok), ctypes.byref(p_bad), None) == -1
+    assert lib.jtvae_gemm_nt_pair(ctypes.byref(p_ok), ctypes.byref(p_ok), None) == 0
+    assert lib.jtvae_select_slab_rows(None, None, 0, None, 0, 450, 452, None) in (0, -1)
+    assert lib.jtvae_row_dot(None, None, None, None, 0, 450, 452, None) == 0
 
 
 def test_modules_refuse_cpu():
