@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=385)
     ap.add_argument("--seed", type=int, default=1234, help="seed of the synthetic batch (rank r uses seed + r)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="molecules in the CPU baseline's sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--detail", action="store_true", help="print a per-shape GEMM table to stderr")
     ap.add_argument("--mode", default="train", choices=("train", "encode", "train_assm"),
@@ -251,7 +252,7 @@ def main():
         out["kernels"] = kernels
         out["kernel_ms_sum"] = round(sum(k["ms_per_step"] for k in kernels), 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(1234, args.vocab)
+        out["cpu_baseline"] = cpu_baseline(1234, args.vocab, sample_b=args.cpu_sample)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
