@@ -146,7 +146,14 @@ def check(rc: int, what: str) -> None:
         raise JtvaeError("%s failed: %s (code %d)" % (what, lib.jtvae_error_string(rc).decode(), rc))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr() -> int:
+    """hipStream_t of PyTorch's current stream on the current device (0 = the null stream).
+    Called once per launch, so it takes the direct binding when this PyTorch has it."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
