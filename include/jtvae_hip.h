@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 1
+#define JTVAE_ABI_VERSION 2
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -120,6 +120,21 @@ size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K);
 int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
                   const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N,
                   int32_t K, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* jtvae_gemm_tn without a workspace argument and without any allocation: the slab partials go to a
+ * fixed array in device memory that the library holds on every GPU it runs on until the process
+ * ends (jtvae_gemm_tn_static_max_bytes() = 48 MiB: enough for every N, K <= 450 product at any M).
+ * It has no counterpart in the reference; it is for callers that cannot allocate (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same slab plan as
+ * jtvae_gemm_tn, so results are bit-identical to it.  A product whose partials need more than the
+ * array holds is rejected with JTVAE_E_WORKSPACE before any launch.  All calls on one GPU share the
+ * array: calls that overlap on one GPU (two streams, two threads) race; issue them on one stream.
+ * The first call on a device resolves the array's address (hipGetSymbolAddress), later calls only
+ * launch. */
+size_t jtvae_gemm_tn_static_max_bytes(void);
+int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
+                         const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N,
+                         int32_t K, int32_t accumulate, void* stream);
 
 /* out[c] (+)= sum_m X[m,c] for c < N (bias gradients), fixed summation order.
  * workspace: jtvae_colsum_workspace_bytes(M,N). */

@@ -21,6 +21,7 @@
 // (four waves per SIMD) are resident per CU: the matrix pipe of a SIMD then always has
 // a wave with MFMAs to issue while the others sit in a barrier or stage the next tile.
 #include <cstdlib>
+#include <mutex>
 
 #include "jtvae_common.h"
 #include "../../include/jtvae_hip.h"
@@ -52,6 +53,17 @@ extern "C" __device__ unsigned long long* jtvae_trace_buf = nullptr;  // [blocks
 #define TRACE_MARK(slot) do {} while (0)
 #define TRACE_HWID(slot) do {} while (0)
 #endif
+
+// Slab partials of jtvae_gemm_tn_static: a fixed array in device memory, one copy per GPU, held for
+// the life of the process.  48 MiB holds the partials of every N, K <= 450 product for any M (at most
+// 52 slabs of 450 x 452 floats).  In host code `tn_scratch` is only a handle for the symbol: the
+// address a kernel may use comes from hipGetSymbolAddress, once per device.
+constexpr size_t TN_SCRATCH_BYTES = (size_t)48 << 20;
+constexpr int TN_MAX_DEVICES = 64;
+static __device__ __align__(256) unsigned char tn_scratch[TN_SCRATCH_BYTES];
+static void* tn_scratch_ptr[TN_MAX_DEVICES];
+static std::mutex tn_scratch_mutex;
+
 
 namespace {
 
@@ -848,6 +860,49 @@ void launch_nt_any(const NtArgs& a, bool vec, hipStream_t s) {
     launch_nt<false, false, 3>(a, s);
 }
 
+int gemm_tn_run(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
+                const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N, int32_t K,
+                int32_t accumulate, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  if (M < 0 || N <= 0 || K <= 0 || ldx < N || ldy < K || lddw < K) return JTVAE_E_SHAPE;
+  if (!X || !Y || !dW || !workspace) return JTVAE_E_NULL;
+  const int ones_col = dbias ? 1 : 0;
+  TnPlan p = tn_plan(M, N, K, ones_col);
+  if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float)) return JTVAE_E_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 15) return JTVAE_E_ALIGN;
+  TnArgs a;
+  a.X = X; a.Y = Y; a.x_rows = x_rows; a.y_rows = y_rows; a.P = (float*)workspace;
+  a.ldx = ldx; a.ldy = ldy; a.ldp = p.ldp;
+  a.M = M; a.N = N; a.K = K;
+  a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.rows_per_split = p.rows_per_split;
+  a.ones_col = ones_col;
+  int blocks = p.tiles_n * p.tiles_k * p.splits;
+  if (aligned16(X, ldx) && aligned16(Y, ldy))
+    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+  long total = (long)N * (K + ones_col);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.P, p.splits, N,
+                     K, p.ldp, dW, lddw, dbias, accumulate);
+  return launch_status();
+}
+
+int tn_scratch_for_current_device(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= TN_MAX_DEVICES) return JTVAE_E_RANGE;
+  std::lock_guard<std::mutex> lock(tn_scratch_mutex);
+  if (!tn_scratch_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(tn_scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!p) return JTVAE_E_NULL;
+    tn_scratch_ptr[dev] = p;
+  }
+  *out = tn_scratch_ptr[dev];
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -909,28 +964,25 @@ size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
 int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
                   const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N, int32_t K,
                   int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream) {
-  if (M < 0 || N <= 0 || K <= 0 || ldx < N || ldy < K || lddw < K) return JTVAE_E_SHAPE;
-  if (!X || !Y || !dW || !workspace) return JTVAE_E_NULL;
-  const int ones_col = dbias ? 1 : 0;
-  TnPlan p = tn_plan(M, N, K, ones_col);
-  if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float)) return JTVAE_E_WORKSPACE;
-  if (reinterpret_cast<uintptr_t>(workspace) & 15) return JTVAE_E_ALIGN;
-  TnArgs a;
-  a.X = X; a.Y = Y; a.x_rows = x_rows; a.y_rows = y_rows; a.P = (float*)workspace;
-  a.ldx = ldx; a.ldy = ldy; a.ldp = p.ldp;
-  a.M = M; a.N = N; a.K = K;
-  a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.rows_per_split = p.rows_per_split;
-  a.ones_col = ones_col;
-  hipStream_t s = (hipStream_t)stream;
-  int blocks = p.tiles_n * p.tiles_k * p.splits;
-  if (aligned16(X, ldx) && aligned16(Y, ldy))
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
-  long total = (long)N * (K + ones_col);
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.P, p.splits, N,
-                     K, p.ldp, dW, lddw, dbias, accumulate);
-  return launch_status();
+  return gemm_tn_run(X, ldx, x_rows, Y, ldy, y_rows, dW, lddw, dbias, M, N, K, accumulate, workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+size_t jtvae_gemm_tn_static_max_bytes(void) { return TN_SCRATCH_BYTES; }
+
+int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
+                         const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N,
+                         int32_t K, int32_t accumulate, void* stream) {
+  if (M < 0 || N <= 0 || K <= 0) return JTVAE_E_SHAPE;
+  // same slab plan as jtvae_gemm_tn, so the result is bit-identical to it
+  if (jtvae_gemm_tn_workspace_bytes(M, N, K) > TN_SCRATCH_BYTES) return JTVAE_E_WORKSPACE;
+  void* ws = nullptr;
+  const int rc = tn_scratch_for_current_device(&ws);
+  if (rc != 0) return rc;
+  // every partial the slab sum reads is written by this call's product kernel first, so the
+  // contents the previous call left in the array never need clearing
+  return gemm_tn_run(X, ldx, x_rows, Y, ldy, y_rows, dW, lddw, dbias, M, N, K, accumulate, ws, TN_SCRATCH_BYTES,
+                     (hipStream_t)stream);
 }
 
 size_t jtvae_colsum_workspace_bytes(int32_t M, int32_t N) {

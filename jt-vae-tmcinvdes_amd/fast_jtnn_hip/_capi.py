@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Epilogue(C.Structure):
@@ -91,6 +91,8 @@ SIGNATURES = {
     "jtvae_gemm_tn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "jtvae_gemm_tn": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _sz,
                                 _vp]),
+    "jtvae_gemm_tn_static_max_bytes": (_sz, []),
+    "jtvae_gemm_tn_static": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
     "jtvae_colsum_workspace_bytes": (_sz, [_i32, _i32]),
     "jtvae_colsum": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "jtvae_pack_batch": (C.c_int, [C.POINTER(PackItem), _i32, _vp]),
