@@ -11,10 +11,11 @@ Follows:
   fast_jtnn/jtmpn.py:113-183    JTMPN.tensorize
   fast_jtnn/datautils.py:150-161 candidate list / batch_idx
 
-Pinned by: tests/golden (JTNNEncoder.tensorize_nodes is executed from the
-reference itself there; the two RDKit-bound tensorizers cannot run without
-RDKit, so for them this restatement is pinned by the golden forward outputs the
-reference produced from these very tables).
+Pinned by: tests/golden.  All tables stored there were built by the reference's own
+tensorizers (JTNNEncoder.tensorize as it is; MPN.tensorize and JTMPN.tensorize with
+their RDKit accessors answered by duck-typed molecule objects, see
+tests/golden/make_golden.py), and the generator asserts that this restatement
+produces the same tables bit for bit.
 """
 import torch
 

@@ -114,3 +114,38 @@ def make_hip_model(g, device):
     m = JTNNVAE(synthetic.FakeVocab(g.V), g.H, g.L, g.dT, g.dG)
     synthetic.fill_params(list(m.named_parameters()), seed=g.seed, bias_scale=g.bias_scale)
     return m.to(device)
+
+
+def make_oracle_vae(g, prop_modes=None):
+    """Oracle of the whole training-side model (decoder, assembly loss, property heads)."""
+    from fast_jtnn_hip import synthetic
+    from oracle.ref_vae import OracleJTNNVAE, OracleJTpropVAE
+
+    if prop_modes is None:
+        m = OracleJTNNVAE(g.V, g.H, g.L, g.dT, g.dG)
+    else:
+        m = OracleJTpropVAE(g.V, g.H, g.L, g.dT, g.dG, prop_modes)
+    synthetic.fill_params(list(m.named_parameters()), seed=g.seed, bias_scale=g.bias_scale)
+    return m
+
+
+def golden_x_batch(g, device=None):
+    """(trees, jtenc_holder, mpn_holder, (jtmpn_holder, batch_idx)) of a golden case, on fresh trees
+    (the decoder rewires node.neighbors, so every forward call needs its own)."""
+    return (g.trees(), g.jtenc_holder(), g.mpn_holder(), (g.jtmpn_holder(), g.batch_idx()))
+
+
+def check_grad_stats(z, tag, named_params, tol_norm, tol_head):
+    """Per-parameter gradient norm and the first 256 gradient values against the golden's."""
+    for name, p in named_params:
+        key = "%snorm/%s" % (tag, name)
+        if key not in z.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        ref = float(z[key])
+        got = float(p.grad.double().norm())
+        assert abs(got - ref) <= tol_norm * max(ref, 1e-6), (name, got, ref)
+        head_ref = z["%shead/%s" % (tag, name)]
+        if np.abs(head_ref).max() > 1e-8:
+            assert rel_err(p.grad.detach().reshape(-1)[:256].cpu().numpy(), head_ref) < tol_head, name

@@ -14,10 +14,21 @@ mean/log-var, bilinear assembly scores, a scalar loss and gradient statistics).
 Weights are not stored: they are refilled from the seed by
 ``fast_jtnn_hip.synthetic.fill_params`` and pinned by a sha256.
 
-The junction-tree tables come from the reference's own
-``JTNNEncoder.tensorize``.  ``MPN.tensorize`` / ``JTMPN.tensorize`` need RDKit,
-so their tables come from oracle/ref_tensorize.py; the golden forward outputs
-are the reference's answer on exactly those tables.
+All index tables come from the reference's own tensorizers.
+``JTNNEncoder.tensorize`` runs as it is.  ``MPN.tensorize`` / ``JTMPN.tensorize``
+(fast_jtnn/mpn.py:110-161, fast_jtnn/jtmpn.py:113-183) read molecules through a
+handful of RDKit accessors; here those accessors are answered by duck-typed
+molecule objects built from the synthetic graphs (``get_mol`` /
+``Chem.MolFromSmiles`` return the object, ``atom_features`` / ``bond_features``
+return its stored feature rows), so the reference's own numbering loops produce
+the tables that are stored.
+
+Second part of every file: the reference's training-side results on the same
+batch - ``JTNNVAE.forward`` (fast_jtnn/jtnn_vae.py:85-103) with the noise of
+``rsample`` recorded, its pieces (both KL terms, the decoder's word / topology
+loss and accuracy, the assembly loss and accuracy), the gradient statistics of
+that loss, and ``JTpropVAE.forward`` (fast_jtnn/jtprop_vae.py:361-441) with the
+denticity and isomer heads on a seeded property table.
 """
 import os
 import sys
@@ -52,6 +63,162 @@ def import_reference():
     return fast_jtnn
 
 
+class _Atom:
+    def __init__(self, mol, i):
+        self.mol, self.i = mol, i
+
+    def GetIdx(self):
+        return self.i
+
+    def GetAtomMapNum(self):
+        return int(self.mol.g.atom_nid[self.i])
+
+
+class _Bond:
+    def __init__(self, mol, i):
+        self.mol, self.i = mol, i
+
+    def GetBeginAtom(self):
+        return _Atom(self.mol, int(self.mol.g.bonds[self.i, 0]))
+
+    def GetEndAtom(self):
+        return _Atom(self.mol, int(self.mol.g.bonds[self.i, 1]))
+
+
+class _Mol:
+    """What the reference's tensorizers ask an RDKit molecule for, answered from a synthetic graph."""
+
+    def __init__(self, g):
+        self.g = g
+
+    def GetNumAtoms(self):
+        return int(self.g.atom_feats.shape[0])
+
+    def GetAtoms(self):
+        return [_Atom(self, i) for i in range(self.GetNumAtoms())]
+
+    def GetBonds(self):
+        return [_Bond(self, i) for i in range(self.g.bonds.shape[0])]
+
+
+def patch_tensorizers(ref):
+    """Route the RDKit accessors of MPN.tensorize / JTMPN.tensorize to the duck-typed molecules."""
+    import fast_jtnn.jtmpn as rj
+    import fast_jtnn.mpn as rm
+
+    rm.get_mol = lambda g: _Mol(g)
+    rm.atom_features = lambda a: torch.from_numpy(a.mol.g.atom_feats[a.i].copy())
+    rm.bond_features = lambda b: torch.from_numpy(b.mol.g.bond_feats[b.i].copy())
+    rj.Chem.MolFromSmiles = lambda g: _Mol(g)
+    rj.Chem.Kekulize = lambda m: None
+    rj.atom_features = lambda a: torch.from_numpy(a.mol.g.atom_feats[a.i].copy())
+    rj.bond_features = lambda b: torch.from_numpy(b.mol.g.bond_feats[b.i].copy())
+
+
+class record_calls:
+    """Records what torch.randn_like, model.rsample and model.assm return during one forward call."""
+
+    def __init__(self, model):
+        self.model, self.eps, self.rsample, self.assm, self.dec = model, [], [], [], []
+
+    def __enter__(self):
+        self._randn = torch.randn_like
+        m = self.model
+
+        def randn_like(t, *a, **k):
+            e = self._randn(t, *a, **k)
+            self.eps.append(e.clone())
+            return e
+        torch.randn_like = randn_like
+        self._rs, self._as = m.rsample, m.assm
+        m.rsample = lambda *a: self._keep(self.rsample, self._rs(*a))
+        m.assm = lambda *a: self._keep(self.assm, self._as(*a))
+        self._hook = m.decoder.register_forward_hook(lambda mod, i, o: self.dec.append(o))
+        return self
+
+    @staticmethod
+    def _keep(lst, out):
+        lst.append(out)
+        return out
+
+    def __exit__(self, *exc):
+        torch.randn_like = self._randn
+        del self.model.rsample, self.model.assm  # instance attributes shadowing the methods
+        self._hook.remove()
+        return False
+
+
+def grad_stats(model, out, tag):
+    for pname, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().reshape(-1)
+        out["%snorm/%s" % (tag, pname)] = np.float64(g.double().norm().item())
+        out["%shead/%s" % (tag, pname)] = g[:256].numpy().copy()
+
+
+FWD_BETA = 0.3
+
+
+def training_side(ref, synthetic, case, holders, out):
+    """JTNNVAE.forward / JTpropVAE.forward of the reference on the case's batch."""
+    name, seed, B, mean_atoms, H, L, dT, dG, V, bias = case
+    jtenc_holder, mpn_holder, jtmpn_holder, batch_idx = holders
+    vocab = synthetic.FakeVocab(V)
+
+    def fresh_batch():  # the decoder rewires node.neighbors (jtnn_dec.py:63-64,126): one batch per call
+        return synthetic.make_batch(seed, B, vocab_size=V, mean_atoms=mean_atoms, with_cands=True)
+
+    model = ref.JTNNVAE(vocab, H, L, dT, dG)
+    synthetic.fill_params(list(model.named_parameters()), seed=seed, bias_scale=bias)
+    model.zero_grad()
+    torch.manual_seed(1000 + seed)
+    with record_calls(model) as rec:
+        loss, kl, wacc, tacc, sacc = model((fresh_batch(), jtenc_holder, mpn_holder, (jtmpn_holder, batch_idx)),
+                                           FWD_BETA)
+    loss.backward()
+    (z_tree, tree_kl), (z_mol, mol_kl) = rec.rsample
+    word_loss, topo_loss, word_acc, topo_acc = rec.dec[0]
+    assm_loss, assm_acc = rec.assm[0]
+    out.update({
+        "fwd_beta": np.float64(FWD_BETA),
+        "fwd_eps_tree": rec.eps[0].numpy(), "fwd_eps_mol": rec.eps[1].numpy(),
+        "fwd_loss": np.float64(loss.item()), "fwd_kl": np.float64(kl),
+        "fwd_tree_kl": np.float64(tree_kl.item()), "fwd_mol_kl": np.float64(mol_kl.item()),
+        "fwd_z_tree": z_tree.detach().numpy(), "fwd_z_mol": z_mol.detach().numpy(),
+        "fwd_word_loss": np.float64(word_loss.item()), "fwd_topo_loss": np.float64(topo_loss.item()),
+        "fwd_word_acc": np.float64(word_acc), "fwd_topo_acc": np.float64(topo_acc),
+        "fwd_assm_loss": np.float64(assm_loss.item()), "fwd_assm_acc": np.float64(assm_acc),
+        "fwd_accs": np.asarray([wacc, tacc, sacc], dtype=np.float64),
+    })
+    grad_stats(model, out, "fg")
+    print("   forward: loss %.6f kl %.6f word %.6f topo %.6f assm %.6f accs %.3f %.3f %.3f"
+          % (loss.item(), kl, word_loss.item(), topo_loss.item(), assm_loss.item(), wacc, tacc, sacc))
+
+    if B < 2:
+        return  # .squeeze() of the one-row head outputs (jtprop_vae.py:397,408) breaks the BCE shape check
+    modes = ["denticity", "isomer"]
+    pmodel = ref.JTpropVAE(vocab, H, L, dT, dG, modes)
+    synthetic.fill_params(list(pmodel.named_parameters()), seed=seed, bias_scale=bias)
+    rs = np.random.RandomState(500 + seed)
+    props = np.stack([rs.standard_normal(B), rs.standard_normal(B) * 0.5, rs.randint(0, 2, size=B),
+                      rs.randint(0, 3, size=B)], axis=1).astype(np.float32)
+    pmodel.zero_grad()
+    torch.manual_seed(2000 + seed)
+    with record_calls(pmodel) as rec:
+        ploss, log_metrics = pmodel((fresh_batch(), torch.FloatTensor(props), jtenc_holder, mpn_holder,
+                                     (jtmpn_holder, batch_idx)), FWD_BETA)
+    ploss.backward()
+    out.update({
+        "prop_table": props, "prop_eps_tree": rec.eps[0].numpy(), "prop_eps_mol": rec.eps[1].numpy(),
+        "prop_loss": np.float64(ploss.item()),
+        "prop_metric_names": np.asarray(list(log_metrics.keys())),
+        "prop_metrics": np.asarray([float(v) for v in log_metrics.values()], dtype=np.float64),
+    })
+    grad_stats(pmodel, out, "pg")
+    print("   JTpropVAE: loss %.6f %s" % (ploss.item(), {k: round(float(v), 4) for k, v in log_metrics.items()}))
+
+
 def projection(shape, seed):
     rs = np.random.RandomState(seed)
     return torch.from_numpy(rs.standard_normal(shape).astype(np.float32))
@@ -59,11 +226,13 @@ def projection(shape, seed):
 
 def main():
     ref = import_reference()
+    patch_tensorizers(ref)
     from fast_jtnn_hip import synthetic
     from oracle import ref_tensorize
 
     torch.set_num_threads(8)
-    for name, seed, B, mean_atoms, H, L, dT, dG, V, bias in CASES:
+    for case in CASES:
+        name, seed, B, mean_atoms, H, L, dT, dG, V, bias = case
         batch = synthetic.make_batch(seed, B, vocab_size=V, mean_atoms=mean_atoms, with_cands=True)
         vocab = synthetic.FakeVocab(V)
         model = ref.JTNNVAE(vocab, H, L, dT, dG)
@@ -71,9 +240,14 @@ def main():
 
         # junction-tree tables: the reference's own tensorizer
         jtenc_holder, mess_dict = ref.JTNNEncoder.tensorize(batch)
-        mpn_holder = ref_tensorize.mpn_tensorize([t.mol for t in batch])
-        cands, batch_idx = ref_tensorize.collect_candidates(batch)
-        jtmpn_holder = ref_tensorize.jtmpn_tensorize(cands, mess_dict)
+        # molecular-graph and candidate-graph tables: the reference's own loops on duck-typed molecules
+        mpn_holder = ref.MPN.tensorize([t.mol for t in batch])
+        cands, batch_idx = ref_tensorize.collect_candidates(batch)  # datautils.py:150-161 (needs RDKit-free code only)
+        jtmpn_holder = ref.JTMPN.tensorize([(c, c.all_nodes, c.ctr_node) for c in cands], mess_dict)
+        for a, b in zip(mpn_holder[:4], ref_tensorize.mpn_tensorize([t.mol for t in batch])[:4]):
+            assert torch.equal(a, b), "the restatement of MPN.tensorize differs from the reference"
+        for a, b in zip(jtmpn_holder[:4], ref_tensorize.jtmpn_tensorize(cands, mess_dict)[:4]):
+            assert torch.equal(a, b), "the restatement of JTMPN.tensorize differs from the reference"
 
         model.zero_grad()
         tree_vecs, tree_mess, mol_vecs = model.encode(jtenc_holder, mpn_holder)
@@ -133,6 +307,7 @@ def main():
             g = p.grad.detach().reshape(-1)
             out["gnorm/" + pname] = np.float64(g.double().norm().item())
             out["ghead/" + pname] = g[:256].numpy().copy()
+        training_side(ref, synthetic, case, (jtenc_holder, mpn_holder, jtmpn_holder, batch_idx), out)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print(name, "B", B, "NM", tree_mess.shape[0], "NC", cand_vecs.shape[0], "loss %.6f" % loss.item(),

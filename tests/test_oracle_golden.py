@@ -78,7 +78,8 @@ def test_index_builders_bit_exact(path):
         assert np.array_equal(mess_graph.numpy(), z["mess_graph"])
         assert [tuple(s) for s in scope] == g.scope("jt_scope")
         assert mess_dict == g.mess_dict()
-    # molecular graph and candidate graph: golden tables come from the loop-by-loop restatement
+    # molecular graph and candidate graph: golden tables come from the reference's own MPN.tensorize /
+    # JTMPN.tensorize run on duck-typed molecule objects (tests/golden/make_golden.py)
     fatoms, fbonds, agraph, bgraph, scope = T.mpn_tensorize([t.mol for t in trees])
     assert np.array_equal(fatoms.numpy(), z["fatoms"].astype(np.float32))
     assert np.array_equal(fbonds.numpy(), z["fbonds"].astype(np.float32))
@@ -87,6 +88,13 @@ def test_index_builders_bit_exact(path):
     assert [tuple(s) for s in scope] == g.scope("mpn_scope")
     cands, batch_idx = synthetic.collect_candidates(trees)
     assert np.array_equal(batch_idx, z["batch_idx"])
+    for impl in (T.mpn_tensorize, R.mpn_tensorize):
+        fa, fb, ag, bg, sc = impl([t.mol for t in trees])
+        assert np.array_equal(fa.numpy(), z["fatoms"].astype(np.float32)) and np.array_equal(ag.numpy(), z["agraph"])
+        assert np.array_equal(fb.numpy(), z["fbonds"].astype(np.float32)) and np.array_equal(bg.numpy(), z["bgraph"])
+    rf, rb, ra, rg, rsc = R.jtmpn_tensorize(cands, g.mess_dict())
+    assert np.array_equal(ra.numpy(), z["c_agraph"]) and np.array_equal(rg.numpy(), z["c_bgraph"])
+    assert np.array_equal(rb.numpy(), z["c_fbonds"].astype(np.float32))
     cf, cb, ca, cg, cs = T.jtmpn_tensorize(cands, g.mess_dict())
     assert np.array_equal(cf.numpy(), z["c_fatoms"].astype(np.float32))
     assert np.array_equal(cb.numpy(), z["c_fbonds"].astype(np.float32))
