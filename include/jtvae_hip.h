@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 2
+#define JTVAE_ABI_VERSION 3
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -241,14 +241,16 @@ int jtvae_gru_bwd_pointwise(const float* dh, const float* z, const float* p, con
 /* Backward of jtvae_gru_gate_gather with respect to h and Uh, over the TRANSPOSED graph
  * (trowptr/tcol: for message j, the messages m that read it), r recomputed:
  *   dUh[i]   = h[j] * sum_e dg[m_e] r_e (1 - r_e)             written compactly (row i of the launch)
- *   dhdir[j] = sum_e ( ds[m_e] + dg[m_e] r_e )              r_e = sigmoid(Pr[wid[m_e]] + Uh[j])
+ *   dhdir[j] = sum_e ( ds[m_e] + dg[m_e] r_e ) (+ dh_ext[j]) r_e = sigmoid(Pr[wid[m_e]] + Uh[j])
  * Readers m_e whose bit t_iter of active[m_e] is clear received no gradient and are skipped
- * (active == NULL: none skipped). */
+ * (active == NULL: none skipped).  dh_ext (or NULL): gradient rows by message id that reach h from
+ * outside the recurrence (the readout, the candidate encoder); it may alias dhdir's target of the
+ * following product, it is only read here. */
 int jtvae_gru_bwd_gather(const float* h, const float* Uh, size_t slab_stride, int32_t t_iter,
                          const int32_t* sf, const uint64_t* active, const float* Pr, const int32_t* wid,
                          const float* dg, const float* ds, const int32_t* trowptr, const int32_t* tcol,
-                         const int32_t* rows, int32_t n_rows, float* dUh, float* dhdir, int32_t H,
-                         int32_t ld, void* stream);
+                         const int32_t* rows, int32_t n_rows, const float* dh_ext, float* dUh, float* dhdir,
+                         int32_t H, int32_t ld, void* stream);
 
 /* out[i] = slab sel[i] of base, row i: collects the final value of every message
  * (sel[i] = min(depth, sf[i])). */

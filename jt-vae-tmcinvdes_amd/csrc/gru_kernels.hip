@@ -120,7 +120,8 @@ __global__ __launch_bounds__(JTVAE_BLOCK) void gru_bwd_gather_kernel(
     const int* __restrict__ sf, const unsigned long long* __restrict__ active, const float* __restrict__ Pr,
     const int* __restrict__ wid, const float* __restrict__ dg, const float* __restrict__ ds,
     const int* __restrict__ trowptr, const int* __restrict__ tcol, const int* __restrict__ rows,
-    float* __restrict__ dUh, float* __restrict__ dhdir, long total, int h4, int H, int ld) {
+    const float* __restrict__ dh_ext, float* __restrict__ dUh, float* __restrict__ dhdir, long total, int h4, int H,
+    int ld) {
   RowPos q = row_pos(total, h4);
   if (!q.ok) return;
   const int j = rows ? rows[q.row] : q.row;
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(JTVAE_BLOCK) void gru_bwd_gather_kernel(
     fma4(acc_h, dgm, r);
     fma4(acc_u, dgm, r * (one - r));
   }
+  if (dh_ext) acc_h = acc_h + *rowp(dh_ext, j, ld, q.c4);  // gradient handed in from outside the recurrence
   *rowp(dUh, q.row, ld, q.c4) = zero_pad(acc_u * hj, q.c4, H);  // compact: row i of this launch
   *rowp(dhdir, j, ld, q.c4) = zero_pad(acc_h, q.c4, H);
 }
@@ -245,7 +247,8 @@ int jtvae_gru_bwd_pointwise(const float* dh, const float* z, const float* p, con
 int jtvae_gru_bwd_gather(const float* h, const float* Uh, size_t slab_stride, int32_t t_iter, const int32_t* sf,
                          const uint64_t* active, const float* Pr, const int32_t* wid, const float* dg,
                          const float* ds, const int32_t* trowptr, const int32_t* tcol, const int32_t* rows,
-                         int32_t n_rows, float* dUh, float* dhdir, int32_t H, int32_t ld, void* stream) {
+                         int32_t n_rows, const float* dh_ext, float* dUh, float* dhdir, int32_t H, int32_t ld,
+                         void* stream) {
   if (n_rows < 0 || H <= 0 || H > ld || t_iter < 0 || t_iter > 63 || (slab_stride & 3)) return JTVAE_E_SHAPE;
   if (n_rows == 0) return 0;
   if (!wid || !trowptr || !tcol) return JTVAE_E_NULL;
@@ -254,13 +257,14 @@ int jtvae_gru_bwd_gather(const float* h, const float* Uh, size_t slab_stride, in
   JT_CHECK(check_rows(Pr, ld));
   JT_CHECK(check_rows(dg, ld));
   JT_CHECK(check_rows(ds, ld));
+  if (dh_ext) JT_CHECK(check_rows(dh_ext, ld));
   JT_CHECK(check_rows(dUh, ld));
   JT_CHECK(check_rows(dhdir, ld));
   int h4 = ld / 4;
   long total = (long)n_rows * h4;
   hipLaunchKernelGGL(gru_bwd_gather_kernel, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, h,
                      Uh, slab_stride, t_iter, sf, (const unsigned long long*)active, Pr, wid, dg, ds, trowptr, tcol,
-                     rows, dUh, dhdir, total, h4, H, ld);
+                     rows, dh_ext, dUh, dhdir, total, h4, H, ld);
   return launch_status();
 }
 

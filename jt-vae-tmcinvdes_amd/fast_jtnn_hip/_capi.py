@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Epilogue(C.Structure):
@@ -113,7 +113,7 @@ SIGNATURES = {
     "jtvae_gru_bwd_pointwise": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
                                           _i32, _vp]),
     "jtvae_gru_bwd_gather": (C.c_int, [_vp, _vp, _sz, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
-                                       _vp, _i32, _i32, _vp]),
+                                       _vp, _vp, _i32, _i32, _vp]),
     "jtvae_select_slab_rows": (C.c_int, [_vp, _vp, _sz, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_row_dot": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
 }
@@ -252,7 +252,9 @@ def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0
             ld_aux=0, a_rows=None, c_rows=None, zero_row=-1, aux_sf=None, aux_t=0, aux_slab_stride=0):
     e = Epilogue(bias, add, ld_add, add_idx, act, pre_out, ld_pre, mode, aux0, aux1, out2, ld_aux,
                  a_rows, c_rows, zero_row, aux_sf, aux_t, aux_slab_stride)
-    extra = (1 if add else 0) + (1 if pre_out else 0) + {EPI_PLAIN: 0, EPI_GRU_BLEND: 3, EPI_MUL_ACC: 3}[mode]
+    # an addend looked up through add_idx is a small per-word table (L2-resident): not priced per row
+    extra = (1 if add and not add_idx else 0) + (1 if pre_out else 0) + {EPI_PLAIN: 0, EPI_GRU_BLEND: 3,
+                                                                          EPI_MUL_ACC: 3}[mode]
     _run("gemm_nt", lib.jtvae_gemm_nt, (A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()),
          nbytes=4 * (M * K + N * K + M * N * (1 + extra)), flops=2 * M * N * K,
          tag="M=%d N=%d K=%d mode=%d" % (M, N, K, mode))
@@ -279,7 +281,7 @@ def gemm_nt_pair(p0, p1):
     """Two independent products (see nt_problem) in one launch where the library supports the pair."""
     def price(p):
         e = p._keep
-        extra = (1 if e.add else 0) + (1 if e.pre_out else 0) + (3 if e.mode != EPI_PLAIN else 0)
+        extra = (1 if e.add and not e.add_idx else 0) + (1 if e.pre_out else 0) + (3 if e.mode != EPI_PLAIN else 0)
         return 4 * (p.M * p.K + p.N * p.K + p.M * p.N * (1 + extra)), 2 * p.M * p.N * p.K
     (b0, f0), (b1, f1) = price(p0), price(p1)
     _run("gemm_nt", lib.jtvae_gemm_nt_pair, (C.byref(p0), C.byref(p1), stream_ptr()), nbytes=b0 + b1, flops=f0 + f1,
@@ -350,12 +352,12 @@ def segment_mean_bwd(drows, dout, act, seg, seg_of, n_rows, H, ld, n_seg=0):
 
 def gru_iter0(Pz, Ph, wid, z, p, h1, n_mess, H, ld, pad_row=0):
     _run("gru_iter0", lib.jtvae_gru_iter0, (Pz, Ph, wid, z, p, h1, n_mess, H, ld, pad_row, stream_ptr()),
-         nbytes=4 * H * n_mess * (5 if z else 3) + 4 * n_mess)
+         nbytes=4 * H * n_mess * (3 if z else 1) + 4 * n_mess)  # rows written; the two word tables are L2 hits
 
 
 def gru_gate_gather(h, Uh, slab_stride, t_iter, sf, Pr, wid, rowptr, col, rows, n_rows, s, g, t, H, ld, nnz=None):
-    # rows: h and Uh per edge, the W_r x table row per message, s / g (/ t) written
-    nbytes = 0 if nnz is None else 4 * H * (2 * nnz + n_rows * (1 + (3 if t else 2))) + 4 * (3 * n_rows + nnz)
+    # rows: h and Uh per edge, s / g (/ t) written (the W_r x row comes from the per-word table, an L2 hit)
+    nbytes = 0 if nnz is None else 4 * H * (2 * nnz + n_rows * (3 if t else 2)) + 4 * (3 * n_rows + nnz)
     _run("gru_gate_gather", lib.jtvae_gru_gate_gather,
          (h, Uh, slab_stride, t_iter, sf, Pr, wid, rowptr, col, rows, n_rows, s, g, t, H, ld, stream_ptr()),
          nbytes=nbytes)
@@ -368,12 +370,13 @@ def gru_bwd_pointwise(dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre,
 
 
 def gru_bwd_gather(h, Uh, slab_stride, t_iter, sf, active, Pr, wid, dg, ds, trowptr, tcol, rows, n_rows, dUh,
-                   dhdir, H, ld, nnz=None):
-    # rows: h, Uh read and dUh, dhdir written per message; table row, dg, ds read per edge
-    nbytes = 0 if nnz is None else 4 * H * (4 * n_rows + 3 * nnz) + 4 * (2 * n_rows + 2 * nnz)
+                   dhdir, H, ld, nnz=None, dh_ext=None):
+    # rows: h, Uh (dh_ext) read and dUh, dhdir written per message; dg, ds read per edge (the table row of the
+    # reader's word is an L2 hit and is not priced)
+    nbytes = 0 if nnz is None else 4 * H * ((5 if dh_ext else 4) * n_rows + 2 * nnz) + 4 * (2 * n_rows + 2 * nnz)
     _run("gru_bwd_gather", lib.jtvae_gru_bwd_gather,
-         (h, Uh, slab_stride, t_iter, sf, active, Pr, wid, dg, ds, trowptr, tcol, rows, n_rows, dUh, dhdir, H, ld,
-          stream_ptr()), nbytes=nbytes)
+         (h, Uh, slab_stride, t_iter, sf, active, Pr, wid, dg, ds, trowptr, tcol, rows, n_rows, dh_ext, dUh, dhdir,
+          H, ld, stream_ptr()), nbytes=nbytes)
 
 
 def select_slab_rows(out, base, slab_stride, sel, n_rows, H, ld):

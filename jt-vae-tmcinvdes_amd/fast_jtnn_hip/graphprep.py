@@ -353,6 +353,56 @@ def _prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     )
 
 
+@dataclass
+class DagPrep:
+    """Device-side form of a set of GRU messages over an arbitrary dependency graph without cycles
+    (the teacher-forced decoder: fast_jtnn/jtnn_dec.py:76-147 creates every directed tree edge once,
+    from the messages created before it).  Same fields as the message part of TreePrep."""
+
+    n_mess: int  # including the padding message 0
+    n_words: int
+    words: torch.Tensor
+    word_csr: DeviceCSR
+    word_csr_t: DeviceCSR
+    wid_m: torch.Tensor
+    mcsr: DeviceCSR  # row m: the messages m is computed from, in the reference's neighbour order
+    mcsr_t: DeviceCSR
+    key_m_pieces: DeviceCSR
+    key_m: DeviceCSR
+    vocab_size: int
+    depth: int  # longest dependency chain: the number of GRU levels
+    host: dict = None
+    schedules: dict = None
+
+
+def prepare_message_dag(word_of_mess: np.ndarray, dep_rp: np.ndarray, dep_col: np.ndarray, vocab_size: int,
+                        device) -> DagPrep:
+    """word_of_mess[m]: word id of the node message m leaves from (entry 0 = padding message, any valid word);
+    dep_rp / dep_col: CSR over message ids of the messages each message reads."""
+    with packed_uploads(device):
+        wm = np.asarray(word_of_mess, dtype=np.int64)
+        nm = wm.shape[0]
+        check_range(wm, vocab_size, "message words")
+        m_rp = np.ascontiguousarray(dep_rp, dtype=np.int32)
+        m_col = np.ascontiguousarray(dep_col, dtype=np.int32)
+        check_range(m_col, nm, "message dependencies")
+        mt_rp, mt_col = transpose_csr(m_rp, m_col, nm)
+        words, inv = np.unique(wm, return_inverse=True)
+        nw = words.shape[0]
+        wid_m = inv.astype(np.int64)
+        w_rp = np.arange(nw + 1, dtype=np.int64)
+        wt_rp, wt_col = transpose_csr(w_rp.astype(np.int32), words.astype(np.int32), vocab_size)
+        km_p, km = _key_lists(wid_m, nw, device)
+        depth = int(K.prep_stable_from(m_rp, m_col, 2 ** 30).max()) if nm else 1
+        return DagPrep(
+            n_mess=nm, n_words=nw, words=_dev_i32(words, device),
+            word_csr=upload_csr(w_rp, words, device), word_csr_t=upload_csr(wt_rp, wt_col, device),
+            wid_m=_dev_i32(wid_m, device), mcsr=upload_csr(m_rp, m_col, device),
+            mcsr_t=upload_csr(mt_rp, mt_col, device), key_m_pieces=km_p, key_m=km, vocab_size=vocab_size,
+            depth=depth, host=dict(m_rp=m_rp, m_col=m_col, mt_rp=mt_rp, mt_col=mt_col, wid_m=wid_m, device=device),
+            schedules={})
+
+
 def tree_schedule(prep: TreePrep, T: int, dense: bool = False, mode: str = None) -> TreeSchedule:
     mode = mode or ("dense" if dense else "once")
     key = (T, mode)
@@ -412,6 +462,8 @@ class BackwardSchedule:
     n_u: int
     key_pieces: DeviceCSR  # compact E rows grouped by word-table row
     key: DeviceCSR
+    once: bool = False  # E / J are reverse-dependency levels (each message once), not iterations
+    n_dep: list = None  # once: leading rows of E[L] that read other messages (the rest read nothing)
 
 
 @dataclass
@@ -506,8 +558,94 @@ def build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], wi
         return _build_backward_schedule(sched, seeds, wid_m, n_words, device)
 
 
+def _expand_lists(rp: np.ndarray, col: np.ndarray, rows: np.ndarray) -> np.ndarray:
+    """Concatenation of the CSR lists of ``rows``."""
+    starts, cnt = rp[rows], rp[rows + 1] - rp[rows]
+    tot = int(cnt.sum())
+    if tot == 0:
+        return col[:0]
+    idx = np.repeat(starts - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(tot)
+    return col[idx]
+
+
+def _build_backward_schedule_once(sched: TreeSchedule, seeds: Optional[np.ndarray], wid_m: np.ndarray,
+                                  n_words: int, device) -> BackwardSchedule:
+    """Backward pass of the compute-once schedule: every message that carries gradient is visited once.
+
+    A message's total gradient is what its consumers outside the recurrence hand in plus what the
+    messages that read it pass back, so it is complete once all of those readers have been visited:
+    level 0 holds the messages no gradient-carrying message reads, level L those whose readers all sit
+    below L.  E[L] lists level L (rows that read other messages first: only they have products to
+    propagate), J[L] = E[L] for L >= 1 are the rows whose incoming gradient is gathered first.
+    """
+    h = sched._host
+    nm, sf = h["nm"], h["sf"]
+    m_rp, m_col, mt_rp, mt_col, deg = h["m_rp"], h["m_col"], h["mt_rp"], h["mt_col"], h["deg"]
+    act = np.zeros(nm, dtype=bool)
+    if seeds is None:
+        act[:] = True
+    else:
+        cur = np.unique(seeds.astype(np.int64))
+        act[cur] = True
+        while cur.size:  # closure over "is read by a gradient-carrying message"
+            nxt = np.unique(_expand_lists(m_rp, m_col, cur))
+            cur = nxt[~act[nxt]]
+            act[cur] = True
+    # reverse level = 1 + max over the active readers (0 without one): relaxation over the transposed graph
+    # restricted to active readers
+    if seeds is None:
+        f_rp, f_col = mt_rp, mt_col
+    else:
+        keep = act[mt_col]
+        row_of = np.repeat(np.arange(nm, dtype=np.int64), np.diff(mt_rp))
+        f_col = mt_col[keep]
+        f_rp = np.zeros(nm + 1, dtype=np.int64)
+        np.cumsum(np.bincount(row_of[keep], minlength=nm), out=f_rp[1:])
+    rl = K.prep_stable_from(f_rp, f_col, 2 ** 30).astype(np.int64) - 1
+    n_lev = int(rl[act].max()) + 1 if act.any() else 0
+    order = np.flatnonzero(act)
+    # within a level: rows with inputs first, message order otherwise
+    has_dep = deg[order] > 0
+    order = order[np.lexsort((order, ~has_dep, rl[order]))]
+    lev_cnt = np.bincount(rl[order], minlength=max(n_lev, 1))[:max(n_lev, 1)]
+    lev_off = np.concatenate([[0], np.cumsum(lev_cnt)])
+    tdeg_act = np.diff(f_rp)
+    El, Jl, offE, offJ, n_dep = [], [], [], [], []
+    nJ = 0
+    for L in range(n_lev):
+        r = order[lev_off[L]:lev_off[L + 1]]
+        offE.append(int(lev_off[L]))
+        n_dep.append(int((deg[r] > 0).sum()))
+        rows_t = _dev_i32(r, device)
+        El.append(RowList(rows_t, int(r.size), int(deg[r].sum())))
+        if L == 0:
+            Jl.append(RowList(None, 0))
+            offJ.append(0)
+        else:
+            Jl.append(RowList(rows_t, int(r.size), int(tdeg_act[r].sum())))
+            offJ.append(nJ)
+            nJ += int(r.size)
+    nE = int(order.size)
+    pos = np.arange(nE, dtype=np.int64)
+    dep_rows = deg[order] > 0  # rows with s, g, t state: they contribute to the W_z / W_h products
+    zx, zy = pos[dep_rows], order[dep_rows]
+    lev0 = int(lev_cnt[0]) if n_lev else 0
+    ux, uy = np.arange(nJ, dtype=np.int64), order[lev0:]
+    keys = wid_m[order]
+    kp, kc = _key_lists(keys.astype(np.int64), n_words, device)
+    one = np.zeros(1, dtype=np.int64)
+    return BackwardSchedule(
+        E=El, J=Jl, offE=offE, offJ=offJ, nE=nE, nJ=nJ,
+        active=torch.from_numpy(act.astype(np.int64)).to(device),
+        zx=_dev_i32(zx if zx.size else one, device), zy=_dev_i32(zy if zy.size else one, device), n_z=int(zx.size),
+        ux=_dev_i32(ux if ux.size else one, device), uy=_dev_i32(uy if uy.size else one, device), n_u=int(ux.size),
+        key_pieces=kp, key=kc, once=True, n_dep=n_dep)
+
+
 def _build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], wid_m: np.ndarray, n_words: int,
                              device) -> BackwardSchedule:
+    if sched.mode == "once":
+        return _build_backward_schedule_once(sched, seeds, wid_m, n_words, device)
     h = sched._host
     nm, T, sf = h["nm"], sched.T, h["sf"]
     m_rp, m_col, deg = h["m_rp"], h["m_col"], h["deg"]

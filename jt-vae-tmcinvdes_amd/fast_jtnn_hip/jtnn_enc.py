@@ -84,8 +84,8 @@ class _TreeGRU:
             h_in = hs[t] if slabbed else hs[0]
             h_out = hs[t + 1] if slabbed else hs[0]
             # Uh = U_r h + b for the messages that changed in the last iteration and are read by someone
-            K.gemm_nt(h_in.data_ptr(), ld, Ur.data_ptr(), ld, us[i].data_ptr(), ld, U.n, H, H, bias=bu.data_ptr(),
-                      a_rows=U.ptr(), c_rows=U.ptr())
+            K.gemm_nt(h_in.data_ptr(), ld, Ur.data_ptr(), ld, us[i].data_ptr(), ld, U.n, H, H,
+                      bias=None if bu is None else bu.data_ptr(), a_rows=U.ptr(), c_rows=U.ptr())
             K.gru_gate_gather(hs.data_ptr(), us.data_ptr(), stride, t, sf_p, Pr.data_ptr(), wid_p,
                               mcsr.rowptr.data_ptr(), mcsr.col.data_ptr(), F.ptr(), F.n, ss[i].data_ptr(),
                               gs[i].data_ptr(), ts[i].data_ptr() if train else None, H, ld, nnz=F.nnz)
@@ -119,6 +119,33 @@ class _TreeGRU:
         a_r = K.rows(NM, ld, dev, zero=True)
         ds, dg, dhdir = K.rows(NM, ld, dev), K.rows(NM, ld, dev), K.rows(NM, ld, dev)
         wid_p = wid.data_ptr()
+        if bs.once:
+            # Every gradient-carrying message once, in reverse dependency order: when a level is reached all
+            # messages that read its rows have been visited, so their gathered gradient is complete.  Saved
+            # state has one row per message (slab stride 0); "iteration T" makes the kernels pick the state of
+            # the iteration in which a message settled and treat messages without inputs as s = g = t = 0.
+            for lev, E in enumerate(bs.E):
+                if lev > 0:
+                    du_t = K.ptr(du, bs.offJ[lev] * ld)
+                    # dUh, and dh = (gradient from outside) + direct part, for rows whose readers are done
+                    K.gru_bwd_gather(hs.data_ptr(), us.data_ptr(), stride, 0, sf_p, act_p, Pr.data_ptr(), wid_p,
+                                     dg.data_ptr(), ds.data_ptr(), mcsr_t.rowptr.data_ptr(), mcsr_t.col.data_ptr(),
+                                     E.ptr(), E.n, du_t, dhdir.data_ptr(), H, ld, nnz=bs.J[lev].nnz,
+                                     dh_ext=dh.data_ptr())
+                    K.gemm_nt(du_t, ld, UrT.data_ptr(), ld, dh.data_ptr(), ld, E.n, H, H, add=dhdir.data_ptr(),
+                              ld_add=ld, c_rows=E.ptr())
+                dz_t, dp_t = K.ptr(dz, bs.offE[lev] * ld), K.ptr(dp, bs.offE[lev] * ld)
+                K.gru_bwd_pointwise(dh.data_ptr(), zs.data_ptr(), ps.data_ptr(), ss.data_ptr(), stride, T, sf_p,
+                                    E.ptr(), E.n, dz_t, dp_t, ds.data_ptr(), H, ld, pad_row)
+                nd = bs.n_dep[lev]  # leading rows of the level that read other messages
+                if nd:
+                    K.gemm_nt_pair(
+                        K.nt_problem(dz_t, ld, WzhT.data_ptr(), ld, ds.data_ptr(), ld, nd, H, H, add=ds.data_ptr(),
+                                     ld_add=ld, c_rows=E.ptr()),
+                        K.nt_problem(dp_t, ld, WhhT.data_ptr(), ld, dg.data_ptr(), ld, nd, H, H, mode=K.EPI_MUL_ACC,
+                                     aux0=ts.data_ptr(), out2=a_r.data_ptr(), ld_aux=ld, c_rows=E.ptr(), aux_sf=sf_p,
+                                     aux_t=T, aux_slab_stride=stride))
+            return dz, dp, du, a_r
         for t in range(T - 1, -1, -1):
             E = bs.E[t]
             if E.n == 0:
@@ -293,6 +320,97 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         dE = torch.empty((V, H), dtype=torch.float32, device=dev)
         K.copy_rows(dE_p.data_ptr(), ld, dE.data_ptr(), H, V, H)
         return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None, None
+
+
+class _MessageGRUFunction(torch.autograd.Function):
+    """forward(E, Wz, bz, Wr, br | None, Ur, bu | None, Wh, bh) -> messages [NM, H]
+
+    The GRU of nnutils.GRU / GraphGRU over the messages of a dependency graph without cycles
+    (``graphprep.DagPrep``), each message computed once, level by level.  It serves the teacher-forced
+    tree decoder (fast_jtnn/jtnn_dec.py:76-147 with fast_jtnn/nnutils.py:56-71), whose reset gate has
+    its bias on W_r and none on U_r - the other way round from GraphGRU - hence both are optional.
+    """
+
+    @staticmethod
+    def forward(ctx, E, Wz, bz, Wr, br, Ur_w, bu, Wh, bh, prep, grad_on=True):
+        dev = E.device
+        H = Wr.shape[0]
+        ld = K.round_ld(H)
+        P = prep
+        NM, NW = P.n_mess, P.n_words
+        train = grad_on and any(ctx.needs_input_grad)
+        sched = graphprep.tree_schedule(P, P.depth, mode="once")
+        E_p = as_row_buffer(E, H, ld)
+        Eu = K.rows(NW, ld, dev)
+        K.csr_gather_sum(Eu.data_ptr(), E_p.data_ptr(), E.shape[0], None, P.word_csr.rowptr.data_ptr(),
+                         P.word_csr.col.data_ptr(), NW, H, ld, nnz=NW)
+        Wzx, Wzh, Whx, Whh, Wr_p, Ur_p = pack_weights(
+            [(Wz, 0, H, False), (Wz, H, H, False), (Wh, 0, H, False), (Wh, H, H, False), (Wr, 0, H, False),
+             (Ur_w, 0, H, False)])
+        Pz, Pr, Ph = (K.rows(NW, ld, dev) for _ in range(3))
+        K.gemm_nt(Eu.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NW, H, H, bias=bz.detach().data_ptr())
+        K.gemm_nt(Eu.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NW, H, H,
+                  bias=None if br is None else br.detach().data_ptr())
+        K.gemm_nt(Eu.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NW, H, H, bias=bh.detach().data_ptr())
+        h, st = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p,
+                                 None if bu is None else bu.detach(), Whh, train)
+        if train:
+            ctx.prep, ctx.H, ctx.ld, ctx.st, ctx.sched = P, H, ld, st, sched
+            ctx.keep = (Eu, Pr, Wz, Wr, Ur_w, Wh)
+            ctx.vocab, ctx.has_br, ctx.has_bu = E.shape[0], br is not None, bu is not None
+        return dense_view(h, H)
+
+    @staticmethod
+    def backward(ctx, dmess):
+        P, H, ld, st, sched = ctx.prep, ctx.H, ctx.ld, ctx.st, ctx.sched
+        Eu, Pr, Wz, Wr, Ur_w, Wh = ctx.keep
+        dev = Eu.device
+        NM, NW, V = P.n_mess, P.n_words, ctx.vocab
+        bs = graphprep.backward_schedule(P, sched, all_messages=True)
+        dWz = torch.empty((H, 2 * H), dtype=torch.float32, device=dev)
+        dWh = torch.empty((H, 2 * H), dtype=torch.float32, device=dev)
+        dWr = torch.empty((H, H), dtype=torch.float32, device=dev)
+        dUr = torch.empty((H, H), dtype=torch.float32, device=dev)
+        dbz, dbh, dbr, dbu = (torch.empty((H,), dtype=torch.float32, device=dev) for _ in range(4))
+        WzhT, WhhT, UrT, WzxT, WhxT, WrT = pack_weights(
+            [(Wz, H, H, True), (Wh, H, H, True), (Ur_w, 0, H, True), (Wz, 0, H, True), (Wh, 0, H, True),
+             (Wr, 0, H, True)])
+        dh = K.rows(NM, ld, dev)  # private copy: the backward sweep accumulates into it
+        dm = dmess if dmess.dim() == 2 and dmess.stride(1) == 1 and dmess.stride(0) >= H else dmess.contiguous()
+        K.copy_rows(dm.data_ptr(), dm.stride(0), dh.data_ptr(), ld, NM, H)
+        dz, dp, du, a_r = _TreeGRU.backward(dh, sched, bs, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT, WhhT,
+                                            UrT)
+        if bs.n_z > 0:
+            K.gemm_tn(dz.data_ptr(), ld, st["ss"].data_ptr(), ld, K.ptr(dWz, H), 2 * H, bs.n_z, H, H, False, dev,
+                      x_rows=bs.zx.data_ptr(), y_rows=bs.zy.data_ptr())
+            K.gemm_tn(dp.data_ptr(), ld, st["gs"].data_ptr(), ld, K.ptr(dWh, H), 2 * H, bs.n_z, H, H, False, dev,
+                      x_rows=bs.zx.data_ptr(), y_rows=bs.zy.data_ptr())
+        else:
+            dWz[:, H:].zero_()
+            dWh[:, H:].zero_()
+        if bs.n_u > 0:
+            K.gemm_tn(du.data_ptr(), ld, st["hs"].data_ptr(), ld, dUr.data_ptr(), H, bs.n_u, H, H, False, dev,
+                      x_rows=bs.ux.data_ptr(), y_rows=bs.uy.data_ptr(), dbias=dbu.data_ptr())
+        else:
+            dUr.zero_()
+            dbu.zero_()
+        dPz = _keyed_sum(dz, bs.key_pieces, bs.key, NW, H, ld, dev)
+        dPh = _keyed_sum(dp, bs.key_pieces, bs.key, NW, H, ld, dev)
+        dPr = _keyed_sum(a_r, P.key_m_pieces, P.key_m, NW, H, ld, dev)
+        for dPt, dW, ldw, db in ((dPz, dWz, 2 * H, dbz), (dPh, dWh, 2 * H, dbh), (dPr, dWr, H, dbr)):
+            K.gemm_tn(dPt.data_ptr(), ld, Eu.data_ptr(), ld, dW.data_ptr(), ldw, NW, H, H, False, dev,
+                      dbias=db.data_ptr())
+        dEu = K.rows(NW, ld, dev)
+        for i, (dPt, WT) in enumerate(((dPz, WzxT), (dPh, WhxT), (dPr, WrT))):
+            K.gemm_nt(dPt.data_ptr(), ld, WT.data_ptr(), ld, dEu.data_ptr(), ld, NW, H, H,
+                      add=dEu.data_ptr() if i else None, ld_add=ld)
+        dE_p = K.rows(V, ld, dev)
+        K.csr_gather_sum(dE_p.data_ptr(), dEu.data_ptr(), NW, None, P.word_csr_t.rowptr.data_ptr(),
+                         P.word_csr_t.col.data_ptr(), V, H, ld, nnz=NW)
+        dE = torch.empty((V, H), dtype=torch.float32, device=dev)
+        K.copy_rows(dE_p.data_ptr(), ld, dE.data_ptr(), H, V, H)
+        return (dE, dWz, dbz, dWr, dbr if ctx.has_br else None, dUr, dbu if ctx.has_bu else None, dWh, dbh, None,
+                None)
 
 
 class GraphGRU(nn.Module):

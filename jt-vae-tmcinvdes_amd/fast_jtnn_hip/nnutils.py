@@ -44,6 +44,39 @@ def gather_sum(source: torch.Tensor, index) -> torch.Tensor:
     return dense_view(out, H)
 
 
+class _CsrGatherSum(torch.autograd.Function):
+    """out[i] = sum of source rows csr.col[csr.rowptr[i] : csr.rowptr[i+1]]; backward over csr_t."""
+
+    @staticmethod
+    def forward(ctx, source, csr, csr_t):
+        H = source.shape[1]
+        ld = K.round_ld(H)
+        with torch.cuda.device(source.device):
+            src = as_row_buffer(source, H, ld)
+            out = K.rows(csr.n_rows, ld, source.device)
+            K.csr_gather_sum(out.data_ptr(), src.data_ptr(), source.shape[0], None, csr.rowptr.data_ptr(),
+                             csr.col.data_ptr(), csr.n_rows, H, ld, nnz=csr.nnz)
+        ctx.csr_t, ctx.H, ctx.ld = csr_t, H, ld
+        return dense_view(out, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        csr_t, H, ld = ctx.csr_t, ctx.H, ctx.ld
+        with torch.cuda.device(dout.device):
+            d = as_row_buffer(dout, H, ld)
+            dsrc = K.rows(csr_t.n_rows, ld, dout.device)
+            K.csr_gather_sum(dsrc.data_ptr(), d.data_ptr(), d.shape[0], None, csr_t.rowptr.data_ptr(),
+                             csr_t.col.data_ptr(), csr_t.n_rows, H, ld, nnz=csr_t.nnz)
+        return dense_view(dsrc, H), None, None
+
+
+def csr_gather_sum(source: torch.Tensor, csr, csr_t) -> torch.Tensor:
+    """Differentiable neighbour sum over a prepared adjacency (``graphprep.DeviceCSR`` and its transpose)."""
+    if source.device.type != "cuda":
+        raise RuntimeError("csr_gather_sum runs on an MI355X only; there is no CPU path")
+    return _CsrGatherSum.apply(source, csr, csr_t)
+
+
 def index_select_ND(source, dim, index):
     """The reference's N-D gather (fast_jtnn/nnutils.py:13-18), kept for callers outside the
     encoder path (it materialises [M, K, H]; the encoder modules never call it)."""
