@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 3
+#define JTVAE_ABI_VERSION 4
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -262,6 +262,13 @@ int jtvae_select_slab_rows(float* out, const float* base, size_t slab_stride, co
 /* score[c] = < q[owner[c]], cand[c] >  for c < n_cand (q = A_assm z_mol rows). */
 int jtvae_row_dot(float* score, const float* q, const int32_t* owner, const float* cand,
                   int32_t n_cand, int32_t H, int32_t ld, void* stream);
+
+/* Backward of jtvae_row_dot (autograd of the bmm of fast_jtnn/jtnn_vae.py:114): dcand[c] = dscore[c] * q[owner[c]]
+ * and dq[b] = sum of dscore[c] * cand[c] over the candidates of owner b, which must be consecutive:
+ * own_ptr (int32 [n_owner + 1]) delimits them, as datautils.py:150-161 lays them out (molecule by molecule). */
+int jtvae_row_dot_bwd(const float* dscore, const float* q, const int32_t* owner, const float* cand,
+                      const int32_t* own_ptr, int32_t n_cand, int32_t n_owner, float* dq, float* dcand, int32_t H,
+                      int32_t ld, void* stream);
 
 /* Candidate-assembly loss: segment s covers scores[seg_ptr[s] .. seg_ptr[s+1]) (the candidates of one
  * tree node), label_pos[s] is the index of the true candidate.  loss_seg[s] = cross entropy of the

@@ -240,6 +240,36 @@ __global__ __launch_bounds__(JTVAE_BLOCK) void row_dot_kernel(float* __restrict_
   if (lane == 0) score[wave] = acc;
 }
 
+// Backward of row_dot.  Rows [0, n_cand): dcand[c] = dscore[c] * q[owner[c]].  Rows [n_cand, n_cand + n_owner):
+// dq[b] = sum over the candidates c of owner b (own_ptr[b] .. own_ptr[b+1], consecutive) of dscore[c] * cand[c],
+// in candidate order.  One thread = one float4 of one output row.
+__global__ __launch_bounds__(JTVAE_BLOCK) void row_dot_bwd_kernel(const float* __restrict__ dscore,
+                                                                  const float* __restrict__ q,
+                                                                  const int* __restrict__ owner,
+                                                                  const float* __restrict__ cand,
+                                                                  const int* __restrict__ own_ptr, int n_cand,
+                                                                  float* __restrict__ dq, float* __restrict__ dcand,
+                                                                  long total, int h4, int H, int ld) {
+  RowPos p = row_pos(total, h4);
+  if (!p.ok) return;
+  if (p.row < n_cand) {
+    const float g = dscore[p.row];
+    *rowp(dcand, p.row, ld, p.c4) = zero_pad(*rowp(q, owner[p.row], ld, p.c4) * g, p.c4, H);
+    return;
+  }
+  const int b = p.row - n_cand;
+  float4 acc = f4zero();
+  for (int c = own_ptr[b]; c < own_ptr[b + 1]; ++c) {
+    const float g = dscore[c];
+    const float4 v = *rowp(cand, c, ld, p.c4);
+    acc.x = fmaf(g, v.x, acc.x);
+    acc.y = fmaf(g, v.y, acc.y);
+    acc.z = fmaf(g, v.z, acc.z);
+    acc.w = fmaf(g, v.w, acc.w);
+  }
+  *rowp(dq, b, ld, p.c4) = zero_pad(acc, p.c4, H);
+}
+
 inline int check_rows(const void* p, int ld) {
   if (!p) return JTVAE_E_NULL;
   if (ld <= 0 || (ld & 3)) return JTVAE_E_ALIGN;
@@ -382,6 +412,22 @@ int jtvae_row_dot(float* score, const float* q, const int32_t* owner, const floa
   long total = (long)n_cand * 64;
   hipLaunchKernelGGL(row_dot_kernel, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, score, q,
                      owner, cand, n_cand, ld / 4, H, ld);
+  return launch_status();
+}
+
+int jtvae_row_dot_bwd(const float* dscore, const float* q, const int32_t* owner, const float* cand,
+                      const int32_t* own_ptr, int32_t n_cand, int32_t n_owner, float* dq, float* dcand, int32_t H,
+                      int32_t ld, void* stream) {
+  if (n_cand < 0 || n_owner < 0 || H <= 0 || H > ld) return JTVAE_E_SHAPE;
+  if (n_cand + n_owner == 0) return 0;
+  if (!dscore || !owner || !own_ptr) return JTVAE_E_NULL;
+  JT_CHECK(check_rows(q, ld));
+  JT_CHECK(check_rows(cand, ld));
+  JT_CHECK(check_rows(dq, ld));
+  JT_CHECK(check_rows(dcand, ld));
+  long total = ((long)n_cand + n_owner) * (ld / 4);
+  hipLaunchKernelGGL(row_dot_bwd_kernel, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, dscore, q,
+                     owner, cand, own_ptr, n_cand, dq, dcand, total, ld / 4, H, ld);
   return launch_status();
 }
 

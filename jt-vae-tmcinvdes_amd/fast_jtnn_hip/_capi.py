@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Epilogue(C.Structure):
@@ -116,6 +116,7 @@ SIGNATURES = {
                                        _vp, _vp, _i32, _i32, _vp]),
     "jtvae_select_slab_rows": (C.c_int, [_vp, _vp, _sz, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_row_dot": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "jtvae_row_dot_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
 }
 
 
@@ -392,6 +393,11 @@ def segment_ce(scores, seg_ptr, label_pos, n_seg, loss_seg, hit_seg, dscores, n_
 def row_dot(score, q, owner, cand, n_cand, H, ld):
     _run("row_dot", lib.jtvae_row_dot, (score, q, owner, cand, n_cand, H, ld, stream_ptr()),
          nbytes=4 * H * 2 * n_cand + 8 * n_cand)
+
+
+def row_dot_bwd(dscore, q, owner, cand, own_ptr, n_cand, n_owner, dq, dcand, H, ld):
+    _run("row_dot_bwd", lib.jtvae_row_dot_bwd, (dscore, q, owner, cand, own_ptr, n_cand, n_owner, dq, dcand, H, ld,
+                                                stream_ptr()), nbytes=4 * H * (3 * n_cand + n_owner) + 12 * n_cand)
 
 
 # ---- host-side index preparation (numpy arrays in host memory; no GPU involved) -----------------

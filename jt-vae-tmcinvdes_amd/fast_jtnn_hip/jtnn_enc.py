@@ -269,7 +269,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         K.gemm_nt(dpre_root.data_ptr(), ld, WohT.data_ptr(), ld, dnsum.data_ptr(), ld, B, H, H)
         dh = K.rows(NM, ld, dev)
         if dmess is not None:
-            dm = dmess if dmess.stride(1) == 1 else dmess.contiguous()
+            dm = dmess if dmess.stride(1) == 1 and dmess.stride(0) >= H else dmess.contiguous()
             K.copy_rows(dm.data_ptr(), dm.stride(0), dh.data_ptr(), ld, NM, H)
         K.csr_gather_sum(dh.data_ptr(), dnsum.data_ptr(), B, None, P.rcsr_t.rowptr.data_ptr(),
                          P.rcsr_t.col.data_ptr(), NM, H, ld, accumulate=dmess is not None, nnz=P.rcsr_t.nnz)
@@ -446,6 +446,9 @@ class GraphGRU(nn.Module):
         NM = mg.shape[0]
         if tuple(h.shape) != (NM, H) or tuple(x.shape) != (NM, H):
             raise ValueError("h and x must be [%d, %d]" % (NM, H))
+        if bool((h != 0).any()):
+            raise ValueError("GraphGRU kernels start from the zero state (as JTNNEncoder does, "
+                             "fast_jtnn/jtnn_enc.py:25): h must be all zeros")
         rp, col = graphprep.padded_to_csr(mg)
         graphprep.check_range(col, NM, "mess_graph")
         mcsr = graphprep.upload_csr(rp, col, dev)

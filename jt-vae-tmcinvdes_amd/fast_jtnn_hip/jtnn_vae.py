@@ -4,19 +4,23 @@ attribute names, so a reference state dict loads unchanged.
 Mirrors the encoder-side surface of ``fast_jtnn.jtnn_vae.JTNNVAE``
 (fast_jtnn/jtnn_vae.py:18-138) and ``fast_jtnn.jtprop_vae.JTpropVAE``
 (fast_jtnn/jtprop_vae.py:27-136, 361-476): ``encode``, ``encode_latent``,
-``rsample``, ``assm`` and ``forward``.  The sequential tree decoder is not part
-of this package: pass any module with the reference decoder's call signature as
-``decoder`` (for example the reference's own ``JTNNDecoder`` running in
-PyTorch-ROCm); without one, ``forward`` returns the encoder-side terms only.
+``rsample``, ``assm`` and ``forward``, with the teacher-forced tree decoder of
+``jtnn_dec.py`` under ``decoder`` as in the reference.  ``decode`` (greedy
+assembly of a molecule, RDKit-driven, batch of one) stays with the reference.
+``rsample`` and ``forward`` accept the noise as an optional argument so that a
+step can be repeated exactly (tests, N-rank == 1-rank checks).
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
+from . import _capi as K
+from . import graphprep
 from .jtmpn import JTMPN
+from .jtnn_dec import JTNNDecoder
 from .jtnn_enc import JTNNEncoder
-from .mpn import MPN
+from .mpn import MPN, as_row_buffer, dense_view
 
 
 class _SegmentCE(torch.autograd.Function):
@@ -59,15 +63,46 @@ def segment_cross_entropy(scores: torch.Tensor, seg_len: torch.Tensor, label_pos
     return loss, hits.sum()
 
 
+class _RowDot(torch.autograd.Function):
+    """score[c] = <q[owner[c]], cand[c]> (the bmm of fast_jtnn/jtnn_vae.py:114 without repeating the
+    projected molecule vector once per candidate); owner's candidates are consecutive (own_ptr)."""
+
+    @staticmethod
+    def forward(ctx, q, cand, owner, own_ptr):
+        H = q.shape[1]
+        ld = K.round_ld(H)
+        with torch.cuda.device(q.device):
+            qp, cp = as_row_buffer(q, H, ld), as_row_buffer(cand, H, ld)
+            score = torch.empty((cand.shape[0],), dtype=torch.float32, device=q.device)
+            K.row_dot(score.data_ptr(), qp.data_ptr(), owner.data_ptr(), cp.data_ptr(), cand.shape[0], H, ld)
+        ctx.keep = (qp, cp, owner, own_ptr, H, ld)
+        return score
+
+    @staticmethod
+    def backward(ctx, dscore):
+        qp, cp, owner, own_ptr, H, ld = ctx.keep
+        nc, nb = cp.shape[0], qp.shape[0]
+        ds = dscore.contiguous().float()
+        with torch.cuda.device(ds.device):
+            dq, dc = K.rows(nb, ld, ds.device), K.rows(nc, ld, ds.device)
+            K.row_dot_bwd(ds.data_ptr(), qp.data_ptr(), owner.data_ptr(), cp.data_ptr(), own_ptr.data_ptr(), nc, nb,
+                          dq.data_ptr(), dc.data_ptr(), H, ld)
+        return dense_view(dq, H), dense_view(dc, H), None, None
+
+
 class JTNNVAE(nn.Module):
     def __init__(self, vocab, hidden_size, latent_size, depthT, depthG, decoder=None):
+        """``decoder``: None builds the in-package teacher-forced decoder (as the reference does,
+        jtnn_vae.py:30-32); False leaves it out (encoder-only use); a module is taken as it is."""
         super(JTNNVAE, self).__init__()
         self.vocab = vocab
         self.hidden_size = hidden_size
         self.latent_size = latent_size = latent_size // 2  # tree and graph halves (jtnn_vae.py:23-25)
 
         self.jtnn = JTNNEncoder(hidden_size, depthT, nn.Embedding(vocab.size(), hidden_size))
-        if decoder is not None:
+        if decoder is None:
+            decoder = JTNNDecoder(vocab, hidden_size, latent_size, nn.Embedding(vocab.size(), hidden_size))
+        if decoder is not False:
             self.decoder = decoder
         self.jtmpn = JTMPN(hidden_size, depthG)
         self.mpn = MPN(hidden_size, depthG)
@@ -140,24 +175,52 @@ class JTNNVAE(nn.Module):
     def assm_scores(self, jtmpn_holder, x_mol_vecs, x_tree_mess):  # jtnn_vae.py:105-114
         jtmpn_holder, batch_idx = jtmpn_holder
         fatoms, fbonds, agraph, bgraph, scope = jtmpn_holder
-        batch_idx = batch_idx.to(x_mol_vecs.device)
+        dev = x_mol_vecs.device
         cand_vecs = self.jtmpn(fatoms, fbonds, agraph, bgraph, scope, x_tree_mess)
-        q = self.A_assm(x_mol_vecs.index_select(0, batch_idx))
-        return (q * cand_vecs).sum(dim=1)
+        nb = x_mol_vecs.shape[0]
+
+        def owners():
+            bi = graphprep._to_np(batch_idx).astype("int64")
+            if bi.size and (bi.min() < 0 or bi.max() >= nb):
+                raise IndexError("batch_idx outside [0, %d)" % nb)
+            if bi.size > 1 and (bi[1:] < bi[:-1]).any():
+                return None  # candidates of a molecule not consecutive: the layout the kernel needs is absent
+            import numpy as np
+            ptr = np.zeros(nb + 1, dtype=np.int64)
+            np.cumsum(np.bincount(bi, minlength=nb), out=ptr[1:])
+            with graphprep.packed_uploads(dev):
+                return graphprep._dev_i32(bi, dev), graphprep._dev_i32(ptr, dev)
+
+        own = graphprep.cached_prep(batch_idx, ("assm_owner", str(dev), nb), owners) \
+            if isinstance(batch_idx, torch.Tensor) else owners()
+        if own is None:
+            q = self.A_assm(x_mol_vecs.index_select(0, batch_idx.to(dev)))
+            return (q * cand_vecs).sum(dim=1)
+        # the bilinear form once per molecule, looked up per candidate inside the kernel
+        return _RowDot.apply(self.A_assm(x_mol_vecs), cand_vecs, own[0], own[1])
 
     def assm(self, mol_batch, jtmpn_holder, x_mol_vecs, x_tree_mess):  # jtnn_vae.py:105-138
         scores = self.assm_scores(jtmpn_holder, x_mol_vecs, x_tree_mess)
-        seg_len, label_pos, tot = [], [], 0
-        for mol_tree in mol_batch:
-            for node in mol_tree.nodes:
-                if len(node.cands) > 1 and not node.is_leaf:
-                    label_pos.append(tot + node.cands.index(node.label))
-                    seg_len.append(len(node.cands))
-                    tot += len(node.cands)
         dev = scores.device
-        loss, acc = segment_cross_entropy(scores, torch.tensor(seg_len, device=dev),
-                                          torch.tensor(label_pos, device=dev))
-        return loss / len(mol_batch), acc.item() * 1.0 / len(seg_len)
+
+        def segments():
+            seg_len, label_pos, tot = [], [], 0
+            for mol_tree in mol_batch:
+                for node in mol_tree.nodes:
+                    if len(node.cands) > 1 and not node.is_leaf:
+                        label_pos.append(tot + node.cands.index(node.label))
+                        seg_len.append(len(node.cands))
+                        tot += len(node.cands)
+            return torch.tensor(seg_len, device=dev), torch.tensor(label_pos, device=dev), len(seg_len)
+
+        key = jtmpn_holder[1]  # one batch_idx tensor per batch: its segments do not change between steps
+        seg_len, label_pos, cnt = graphprep.cached_prep(key, ("assm_segments", str(dev)), segments) \
+            if isinstance(key, torch.Tensor) else segments()
+        if int(seg_len.sum()) != scores.shape[0]:
+            raise ValueError("candidate segments cover %d scores, the holder has %d" % (int(seg_len.sum()),
+                                                                                   scores.shape[0]))
+        loss, acc = segment_cross_entropy(scores, seg_len, label_pos)
+        return loss / len(mol_batch), acc.item() * 1.0 / cnt
 
     def forward(self, x_batch, beta, epsilons=None):  # jtnn_vae.py:85-103
         x_batch, x_jtenc_holder, x_mpn_holder, x_jtmpn_holder = x_batch
@@ -176,31 +239,35 @@ class JTNNVAE(nn.Module):
 
 
 class JTpropVAE(JTNNVAE):
-    """Conditional variant: adds the property regressor on the sampled latent
-    (fast_jtnn/jtprop_vae.py:62-66, 394-397)."""
+    """Conditional variant (fast_jtnn/jtprop_vae.py:27-96, 361-441): property regressor on the sampled
+    latent, optional denticity (binary) and isomer (3-class) heads selected by ``train_mode``."""
 
     def __init__(self, vocab, hidden_size, latent_size, depthT, depthG, train_mode=(), decoder=None):
         super(JTpropVAE, self).__init__(vocab, hidden_size, latent_size, depthT, depthG, decoder=decoder)
         self.propNN = nn.Sequential(nn.Linear(self.latent_size * 2, self.hidden_size), nn.Tanh(),
                                     nn.Linear(self.hidden_size, 2))
-        self.train_mode = tuple(train_mode)
+        self.train_mode = list(train_mode)
         for term in self.train_mode:
             if term == "denticity":
                 self.denticityNN = nn.Sequential(nn.Linear(self.latent_size * 2, self.hidden_size), nn.Sigmoid(),
                                                  nn.Linear(self.hidden_size, 1))
+                self.denticityNN_loss = nn.BCEWithLogitsLoss()
             elif term == "isomer":
                 self.isomerNN = nn.Sequential(nn.Linear(self.latent_size * 2, self.hidden_size), nn.Sigmoid(),
                                               nn.Linear(self.hidden_size, 3))
+                self.isomerNN_loss = nn.CrossEntropyLoss()
             else:
                 raise ValueError("train_mode is not a valid value")
         self.prop_loss = nn.MSELoss()
 
     def forward(self, x_batch, beta, epsilons=None):  # jtprop_vae.py:361-441
         x_batch, x_prop_holder, x_jtenc_holder, x_mpn_holder, x_jtmpn_holder = x_batch
-        length_p = x_prop_holder.shape[1]
+        length_p = len(x_prop_holder[0])
         if length_p not in (2, 3, 4):
             raise ValueError("The correct number of properties could not be unpacked")
         x_tree_vecs, x_tree_mess, x_mol_vecs = self.encode(x_jtenc_holder, x_mpn_holder)
+        dev = x_tree_vecs.device
+        props = torch.as_tensor(x_prop_holder).to(dev, non_blocking=True)
         e_t, e_g = epsilons if epsilons is not None else (None, None)
         z_tree_vecs, tree_kl = self.rsample(x_tree_vecs, self.T_mean, self.T_var, e_t)
         z_mol_vecs, mol_kl = self.rsample(x_mol_vecs, self.G_mean, self.G_var, e_g)
@@ -212,21 +279,20 @@ class JTpropVAE(JTNNVAE):
             word_acc = topo_acc = 0.0
         assm_loss, assm_acc = self.assm(x_batch, x_jtmpn_holder, z_mol_vecs, x_tree_mess)
         all_vec = torch.cat([z_tree_vecs, z_mol_vecs], dim=1)
-        dev = all_vec.device
-        prop_label = x_prop_holder[:, 0:2].to(dev).float()
-        prop_loss = self.prop_loss(self.propNN(all_vec).squeeze(), prop_label)
+        prop_loss = self.prop_loss(self.propNN(all_vec).squeeze(), props[:, 0:2].float())
         loss = word_loss + topo_loss + assm_loss + beta * kl_div + prop_loss
-        log_metrics = {"kl_div": kl_div.item(), "word_acc": word_acc * 100, "topo_acc": topo_acc * 100,
-                       "assm_acc": assm_acc * 100, "prop_loss": prop_loss.item() * 100}
+        extra = {}
         for term in self.train_mode:
-            if term == "denticity":
-                lab = x_prop_holder[:, 2].to(dev).float()
-                dent_loss = nn.functional.binary_cross_entropy_with_logits(self.denticityNN(all_vec).squeeze(), lab)
-                loss = loss + dent_loss
-                log_metrics["dent_loss"] = dent_loss.item() * 100
-            elif term == "isomer":
-                lab = x_prop_holder[:, 3].to(dev).long()
-                isomer_loss = nn.functional.cross_entropy(self.isomerNN(all_vec).squeeze(), lab)
-                loss = loss + isomer_loss
-                log_metrics["isomer_loss"] = isomer_loss.item() * 100
+            if term == "denticity":  # third column (jtprop_vae.py:373-378, 400-409)
+                extra["dent_loss"] = self.denticityNN_loss(self.denticityNN(all_vec).squeeze(), props[:, 2].float())
+            elif term == "isomer":  # fourth column (jtprop_vae.py:376-380, 410-419)
+                extra["isomer_loss"] = self.isomerNN_loss(self.isomerNN(all_vec).squeeze(), props[:, 3].long())
+        for v in extra.values():
+            loss = loss + v
+        # every logged scalar in one device-to-host copy
+        vals = torch.stack([kl_div, prop_loss] + list(extra.values())).tolist()
+        log_metrics = {"kl_div": vals[0], "word_acc": word_acc * 100, "topo_acc": topo_acc * 100,
+                       "assm_acc": assm_acc * 100, "prop_loss": vals[1] * 100}
+        for name, v in zip(extra.keys(), vals[2:]):
+            log_metrics[name] = v * 100
         return loss, log_metrics

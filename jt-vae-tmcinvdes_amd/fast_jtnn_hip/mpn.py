@@ -87,7 +87,7 @@ def as_row_buffer(t: torch.Tensor, H: int, ld: int) -> torch.Tensor:
     src = t.detach()
     if src.dtype != torch.float32:
         src = src.float()
-    if src.dim() != 2 or src.stride(1) != 1:
+    if src.dim() != 2 or src.stride(1) != 1 or src.stride(0) < H:  # e.g. a broadcast gradient (stride 0)
         src = src.reshape(t.shape[0], -1).contiguous()
     K.copy_rows(src.data_ptr(), src.stride(0), buf.data_ptr(), ld, t.shape[0], H)
     return buf

@@ -260,10 +260,11 @@ class OracleJTpropVAE(OracleJTNNVAE):
         t = self.forward_terms(x_batch, x_jtenc_holder, x_mpn_holder, x_jtmpn_holder, epsilons)
         kl_div = t["tree_kl"] + t["mol_kl"]
         all_vec = torch.cat([t["z_tree"], t["z_mol"]], dim=1)
-        prop_loss = self.prop_loss(self.propNN(all_vec).squeeze(), x_prop[:, 0:2])
+        prop_loss = self.prop_loss(self.propNN(all_vec).squeeze(), x_prop[:, 0:2].to(all_vec.dtype))
         for term in self.train_mode:
             if term == "denticity":
-                dent_loss = self.denticityNN_loss(self.denticityNN(all_vec).squeeze(), x_dent.type(torch.FloatTensor))
+                # FloatTensor in the reference; the module's dtype here so that the same code also runs in fp64
+                dent_loss = self.denticityNN_loss(self.denticityNN(all_vec).squeeze(), x_dent.to(all_vec.dtype))
             elif term == "isomer":
                 isomer_loss = self.isomerNN_loss(self.isomerNN(all_vec).squeeze(), x_isomer.type(torch.LongTensor))
         standard_loss = t["word_loss"] + t["topo_loss"] + t["assm_loss"] + beta * kl_div + prop_loss

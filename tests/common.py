@@ -135,8 +135,31 @@ def golden_x_batch(g, device=None):
     return (g.trees(), g.jtenc_holder(), g.mpn_holder(), (g.jtmpn_holder(), g.batch_idx()))
 
 
-def check_grad_stats(z, tag, named_params, tol_norm, tol_head):
-    """Per-parameter gradient norm and the first 256 gradient values against the golden's."""
+def fp64_training_grads(g, prop_modes=None):
+    """Gradients of the golden training step from the oracle's op sequence run in fp64 (same batch, same
+    recorded noise): the yardstick that tells an implementation's rounding from the reference's own.
+    The candidate-graph ReLUs sit behind 20 recurrent fp32 iterations; a unit whose pre-activation is
+    within fp32 rounding of zero switches differently in fp32 and in exact arithmetic, which moves single
+    gradient entries of the reference's own fp32 result by up to a few 1e-3."""
+    z = g.z
+    m = make_oracle_vae(g, prop_modes).double()
+    trees, jt, mp, (cj, bi) = golden_x_batch(g)
+    mp = (mp[0].double(), mp[1].double()) + tuple(mp[2:])
+    cj = (cj[0].double(), cj[1].double()) + tuple(cj[2:])
+    tag = "fwd" if prop_modes is None else "prop"
+    eps = (torch.from_numpy(z[tag + "_eps_tree"]).double(), torch.from_numpy(z[tag + "_eps_mol"]).double())
+    if prop_modes is None:
+        loss = m((trees, jt, mp, (cj, bi)), float(z["fwd_beta"]), epsilons=eps)[0]
+    else:
+        loss = m((trees, torch.from_numpy(z["prop_table"]), jt, mp, (cj, bi)), float(z["fwd_beta"]), epsilons=eps)[0]
+    loss.backward()
+    return {n: p.grad.detach().numpy() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def check_grad_stats(z, tag, named_params, tol_norm, tol_head, exact=None):
+    """Per-parameter gradient norm and the first 256 gradient values against the golden's.  With ``exact``
+    (fp64 gradients of the same step): an entry may differ from the golden by as much as the golden itself
+    differs from the fp64 result (the reference's own rounding), and must match the fp64 result to 1e-4."""
     for name, p in named_params:
         key = "%snorm/%s" % (tag, name)
         if key not in z.files:
@@ -148,4 +171,10 @@ def check_grad_stats(z, tag, named_params, tol_norm, tol_head):
         assert abs(got - ref) <= tol_norm * max(ref, 1e-6), (name, got, ref)
         head_ref = z["%shead/%s" % (tag, name)]
         if np.abs(head_ref).max() > 1e-8:
-            assert rel_err(p.grad.detach().reshape(-1)[:256].cpu().numpy(), head_ref) < tol_head, name
+            head = p.grad.detach().reshape(-1)[:256].cpu().numpy()
+            slack = 0.0
+            if exact is not None:
+                ex = exact[name].reshape(-1)[:256]
+                slack = 1.5 * rel_err(ex, head_ref)
+                assert rel_err(head, ex) < 1e-4, (name, rel_err(head, ex))
+            assert rel_err(head, head_ref) < max(tol_head, slack), (name, rel_err(head, head_ref), slack)

@@ -31,6 +31,9 @@ def test_forward_matches_reference_golden(path):
     assert rel_err(cand.cpu().numpy(), z["cand_vecs"]) < RTOL
     assert rel_err(mean.cpu().numpy(), z["mean"]) < RTOL
     assert rel_err(logvar.cpu().numpy(), z["logvar"]) < RTOL
+    # element by element as well (the bound above is relative to the largest entry of the tensor)
+    assert np.allclose(mean.cpu().numpy(), z["mean"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(logvar.cpu().numpy(), z["logvar"], rtol=1e-4, atol=1e-6)
     assert rel_err(scores.cpu().numpy(), z["scores"]) < RTOL
     assert float(mess[0].abs().max()) == 0.0  # the padding message stays exactly zero
 

@@ -1,0 +1,173 @@
+"""GPU: the training-side callers (rsample, teacher-forced decoder, assembly loss, JTNNVAE.forward,
+JTpropVAE.forward) through the HIP path against what the reference itself returned on the golden
+batches (north-star bound: losses within 1e-4 relative), and against the CPU oracle on larger batches."""
+import numpy as np
+import pytest
+import torch
+
+from common import (RTOL, Golden, check_grad_stats, fp64_training_grads, fro_err, golden_cases, golden_x_batch,
+                    make_hip_model, make_oracle_vae, rel_err)
+
+pytestmark = pytest.mark.gpu
+CASES = golden_cases()
+PROP_CASES = [p for p in CASES if "prop_loss" in np.load(p).files]
+
+
+def close(a, b, tol=RTOL):
+    return abs(float(a) - float(b)) <= tol * max(1.0, abs(float(b)))
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: p.split("/")[-1])
+def test_forward_pieces_match_reference_golden(path):
+    g = Golden(path)
+    z = g.z
+    m = make_hip_model(g, "cuda")
+    trees, jt, mp, cj = golden_x_batch(g)
+    et, eg = torch.from_numpy(z["fwd_eps_tree"]).cuda(), torch.from_numpy(z["fwd_eps_mol"]).cuda()
+    with torch.no_grad():
+        tv, ms, mv = m.encode(jt, mp)
+        z_tree, tree_kl = m.rsample(tv, m.T_mean, m.T_var, et)
+        z_mol, mol_kl = m.rsample(mv, m.G_mean, m.G_var, eg)
+        word_loss, topo_loss, word_acc, topo_acc = m.decoder(trees, z_tree)
+        assm_loss, assm_acc = m.assm(trees, cj, z_mol, ms)
+    assert close(tree_kl.item(), z["fwd_tree_kl"]) and close(mol_kl.item(), z["fwd_mol_kl"])
+    assert rel_err(z_tree.cpu().numpy(), z["fwd_z_tree"]) < RTOL and rel_err(z_mol.cpu().numpy(), z["fwd_z_mol"]) < RTOL
+    assert np.allclose(z_tree.cpu().numpy(), z["fwd_z_tree"], rtol=1e-4, atol=1e-5)
+    assert close(word_loss.item(), z["fwd_word_loss"]) and close(topo_loss.item(), z["fwd_topo_loss"])
+    assert close(assm_loss.item(), z["fwd_assm_loss"])
+    assert abs(word_acc - float(z["fwd_word_acc"])) < 1e-6 and abs(topo_acc - float(z["fwd_topo_acc"])) < 1e-6
+    assert abs(assm_acc - float(z["fwd_assm_acc"])) < 1e-6
+
+
+@pytest.mark.parametrize("path", CASES, ids=lambda p: p.split("/")[-1])
+def test_training_forward_backward_matches_reference_golden(path):
+    g = Golden(path)
+    z = g.z
+    m = make_hip_model(g, "cuda")
+    eps = (torch.from_numpy(z["fwd_eps_tree"]).cuda(), torch.from_numpy(z["fwd_eps_mol"]).cuda())
+    loss, kl, wacc, tacc, sacc = m(golden_x_batch(g), float(z["fwd_beta"]), epsilons=eps)
+    assert close(loss.item(), z["fwd_loss"]) and close(kl, z["fwd_kl"])
+    assert np.allclose([wacc, tacc, sacc], z["fwd_accs"], atol=1e-6)
+    loss.backward()
+    check_grad_stats(z, "fg", m.named_parameters(), 2e-4, 5e-4, exact=fp64_training_grads(g))
+
+
+@pytest.mark.parametrize("path", PROP_CASES, ids=lambda p: p.split("/")[-1])
+def test_conditional_forward_backward_matches_reference_golden(path):
+    from fast_jtnn_hip import JTpropVAE, synthetic
+
+    g = Golden(path)
+    z = g.z
+    m = JTpropVAE(synthetic.FakeVocab(g.V), g.H, g.L, g.dT, g.dG, ["denticity", "isomer"])
+    synthetic.fill_params(list(m.named_parameters()), seed=g.seed, bias_scale=g.bias_scale)
+    m = m.cuda()
+    eps = (torch.from_numpy(z["prop_eps_tree"]).cuda(), torch.from_numpy(z["prop_eps_mol"]).cuda())
+    trees, jt, mp, cj = golden_x_batch(g)
+    loss, metrics = m((trees, torch.from_numpy(z["prop_table"]), jt, mp, cj), float(z["fwd_beta"]), epsilons=eps)
+    assert close(loss.item(), z["prop_loss"])
+    assert list(metrics.keys()) == [str(k) for k in z["prop_metric_names"]]
+    for (k, got), want in zip(metrics.items(), z["prop_metrics"]):
+        assert close(got, want), (k, got, want)
+    loss.backward()
+    check_grad_stats(z, "pg", m.named_parameters(), 2e-4, 5e-4,
+                     exact=fp64_training_grads(g, ["denticity", "isomer"]))
+
+
+def _seeded_training_problem(seed, B, atoms, V=120):
+    from fast_jtnn_hip import synthetic, tensorize as T
+
+    class G:
+        pass
+    g = G()
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = seed, B, 450, 56, 20, 3, V, 0.05
+
+    def x_batch():
+        trees = synthetic.make_batch(seed, B, vocab_size=V, mean_atoms=atoms, with_cands=True)
+        jt, mess_dict = T.jtenc_tensorize(trees)
+        mp = T.mpn_tensorize([t.mol for t in trees])
+        cands, bi = synthetic.collect_candidates(trees)
+        return trees, jt, mp, (T.jtmpn_tensorize(cands, mess_dict), torch.from_numpy(bi))
+    return g, x_batch
+
+
+@pytest.mark.parametrize("seed,B,atoms", [(31, 24, 30.0), (32, 3, 8.0)])
+def test_training_step_matches_oracle_on_fresh_batches(seed, B, atoms):
+    """Loss terms and every gradient tensor of JTNNVAE.forward against the fp32 CPU oracle (decoder weights
+    at the path's 1e-4; encoder-side tensors as in the encoder tests)."""
+    g, x_batch = _seeded_training_problem(seed, B, atoms)
+    hip, ora = make_hip_model(g, "cuda"), make_oracle_vae(g)
+    rs = np.random.RandomState(seed)
+    eps = [torch.from_numpy(rs.standard_normal((B, 28)).astype(np.float32)) for _ in range(2)]
+    la = hip(x_batch(), 0.5, epsilons=[e.cuda() for e in eps])
+    lb = ora(x_batch(), 0.5, epsilons=eps)
+    assert close(la[0].item(), lb[0].item()) and close(la[1], lb[1])
+    assert np.allclose(la[2:], lb[2:], atol=1e-6)
+    la[0].backward()
+    lb[0].backward()
+    pb = dict(ora.named_parameters())
+    for name, p in hip.named_parameters():
+        assert p.grad is not None, name
+        f = fro_err(p.grad.cpu().numpy(), pb[name].grad.numpy())
+        assert f < (1e-3 if name.startswith("jtmpn.") else 2e-4), (name, f)
+
+
+def test_decoder_alone_matches_oracle_and_leaves_the_batch_untouched():
+    g, x_batch = _seeded_training_problem(41, 16, 24.0, V=60)
+    hip, ora = make_hip_model(g, "cuda"), make_oracle_vae(g)
+    rs = np.random.RandomState(5)
+    zt = torch.from_numpy(rs.standard_normal((16, 28)).astype(np.float32))
+    trees_a, trees_b = x_batch()[0], x_batch()[0]
+    order_before = [[y.idx for y in n.neighbors] for t in trees_a for n in t.nodes]
+    za = zt.cuda().requires_grad_(True)
+    zb = zt.clone().requires_grad_(True)
+    a = hip.decoder(trees_a, za)
+    b = ora.decoder(trees_b, zb)
+    assert [[y.idx for y in n.neighbors] for t in trees_a for n in t.nodes] == order_before
+    assert close(a[0].item(), b[0].item()) and close(a[1].item(), b[1].item())
+    assert abs(a[2] - b[2]) < 1e-6 and abs(a[3] - b[3]) < 1e-6
+    (a[0] + 2.0 * a[1]).backward()
+    (b[0] + 2.0 * b[1]).backward()
+    assert fro_err(za.grad.cpu().numpy(), zb.grad.numpy()) < RTOL
+    pb = dict(ora.decoder.named_parameters())
+    for name, p in hip.decoder.named_parameters():
+        assert fro_err(p.grad.cpu().numpy(), pb[name].grad.numpy()) < RTOL, name
+
+
+def test_decoder_edge_cases_single_node_and_two_node_trees():
+    from fast_jtnn_hip import synthetic
+
+    g, _ = _seeded_training_problem(1, 2, 8.0, V=9)
+    g.H, g.L = 32, 8
+    hip, ora = make_hip_model(g, "cuda"), make_oracle_vae(g)
+
+    def trees():
+        rs = np.random.RandomState(0)
+        mol = synthetic.make_mol(rs, 6.0, 1.0, 4, 8)
+        t1 = synthetic.Tree([synthetic.TreeNode(1, 2)], mol)
+        n1, n2 = synthetic.TreeNode(1, 0), synthetic.TreeNode(2, 4)
+        n1.neighbors.append(n2); n2.neighbors.append(n1)
+        out = [t1, synthetic.Tree([n1, n2], mol)]
+        synthetic.set_batch_nodeID(out)
+        return out
+    zt = torch.from_numpy(np.random.RandomState(1).standard_normal((2, 4)).astype(np.float32))
+    for batch in (lambda: trees()[:1], trees):  # one single-node tree alone (no message at all), then both
+        zb = zt[:len(batch())]
+        a = hip.decoder(batch(), zb.cuda())
+        b = ora.decoder(batch(), zb)
+        assert close(a[0].item(), b[0].item()) and close(a[1].item(), b[1].item())
+        assert abs(a[2] - b[2]) < 1e-6 and abs(a[3] - b[3]) < 1e-6
+
+
+def test_broadcast_gradients_reach_the_kernels():
+    """The gradient of tree_vecs.sum(0) / messages.sum(0) is an expanded (stride 0) tensor."""
+    g = Golden(CASES[1])
+    m = make_hip_model(g, "cuda")
+    tv, ms, mv = m.encode(g.jtenc_holder(), g.mpn_holder())
+    w = torch.linspace(-1, 1, g.H, device="cuda")
+    (tv.sum(0).dot(w) + mv.sum(0).dot(w) + ms.sum(0).dot(w)).backward()
+    ref = make_hip_model(g, "cuda")
+    tv2, ms2, mv2 = ref.encode(g.jtenc_holder(), g.mpn_holder())
+    ((tv2 * w).sum() + (mv2 * w).sum() + (ms2 * w).sum()).backward()
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if q.grad is not None:
+            assert torch.equal(p.grad, q.grad), n
