@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 4
+#define JTVAE_ABI_VERSION 5
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -301,6 +301,22 @@ int jtvae_prep_stable_from(const int32_t* rowptr, const int32_t* col, int64_t n,
  * gradients): order = item ids sorted by key, ties in input order; keyptr: [n_keys+1]. */
 int jtvae_prep_group_by_key(const int32_t* keys, int64_t n, int64_t n_keys, int32_t* keyptr,
                             int32_t* order);
+
+/* Index form of the teacher-forced decoder traces of a batch (fast_jtnn/jtnn_dec.py:59-167, dfs :299-305),
+ * from the junction-tree tables: directed edge m runs src[m] -> dst[m] (ids 1 .. n_mess-1 in the numbering of
+ * fast_jtnn/jtnn_enc.py:58-62; 0 = padding message), wid = word of every node, roots = first node of every
+ * tree.  Out: dep_rp [n_mess+1] / dep_col: the edges each edge's hidden row is computed from (neighbours so
+ * far minus the target, creation order); per step row (ordered step by step, trees in batch order, the final
+ * stop at every root last): stop_rp / stop_col (all edges that have reached the current node), stop_word,
+ * stop_ctx (tree), stop_target (1 = down, 0 = back); pred_mess [n_down] (edge whose row predicts the child),
+ * pred_ctx / pred_target [n_trees + n_down] (roots first).  Row arrays need room for n_mess - 1 + n_trees
+ * entries; dep_cap / stop_cap = capacity of dep_col / stop_col.  counts[4] = {steps, n_down, nnz(dep),
+ * nnz(stop)}.  JTVAE_E_RANGE: an index is out of range or the edges do not form trees. */
+int jtvae_prep_decoder_plan(const int32_t* src, const int32_t* dst, int64_t n_mess, const int32_t* wid,
+                            int64_t n_nodes, const int32_t* roots, int64_t n_trees, int32_t* dep_rp,
+                            int32_t* dep_col, int64_t dep_cap, int32_t* stop_rp, int32_t* stop_col,
+                            int64_t stop_cap, int32_t* stop_word, int32_t* stop_ctx, float* stop_target,
+                            int32_t* pred_mess, int32_t* pred_ctx, int32_t* pred_target, int64_t* counts);
 
 #ifdef __cplusplus
 }

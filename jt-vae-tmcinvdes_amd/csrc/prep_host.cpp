@@ -99,4 +99,142 @@ int jtvae_prep_group_by_key(const int32_t* keys, int64_t n, int64_t n_keys, int3
   return 0;
 }
 
+// Index form of the teacher-forced decoder traces of a batch (fast_jtnn/jtnn_dec.py:59-167, dfs :299-305),
+// from the junction-tree tables alone.  Directed tree edge m runs src[m] -> dst[m] (ids 1 .. n_mess-1 as
+// JTNNEncoder.tensorize numbers them: node by node, neighbours in order; 0 is the padding message).  Every
+// tree is walked depth first from its root; step t of tree i creates the hidden row of one edge (x -> y)
+// from the rows that reached x before it, minus the one that came from y.  Rows of the step tables are
+// ordered step by step, trees in batch order inside a step - the order in which the reference concatenates
+// them - and the final stop decision at every root comes last.
+int jtvae_prep_decoder_plan(const int32_t* src, const int32_t* dst, int64_t n_mess, const int32_t* wid,
+                            int64_t n_nodes, const int32_t* roots, int64_t n_trees, int32_t* dep_rp,
+                            int32_t* dep_col, int64_t dep_cap, int32_t* stop_rp, int32_t* stop_col,
+                            int64_t stop_cap, int32_t* stop_word, int32_t* stop_ctx, float* stop_target,
+                            int32_t* pred_mess, int32_t* pred_ctx, int32_t* pred_target, int64_t* counts) {
+  if (n_mess < 1 || n_nodes < 0 || n_trees < 0 || dep_cap < 0 || stop_cap < 0) return JTVAE_E_SHAPE;
+  if (!src || !dst || !wid || !roots || !dep_rp || !stop_rp || !stop_word || !stop_ctx || !stop_target ||
+      !pred_mess || !pred_ctx || !pred_target || !counts)
+    return JTVAE_E_NULL;
+  // outgoing edges of every node, in id order (= neighbour order)
+  std::vector<int32_t> out_ptr((size_t)n_nodes + 1, 0), out_edge((size_t)n_mess);
+  for (int64_t m = 1; m < n_mess; ++m) {
+    if (src[m] < 0 || src[m] >= n_nodes || dst[m] < 0 || dst[m] >= n_nodes) return JTVAE_E_RANGE;
+    ++out_ptr[(size_t)src[m] + 1];
+  }
+  for (int64_t x = 0; x < n_nodes; ++x) out_ptr[(size_t)x + 1] += out_ptr[(size_t)x];
+  {
+    std::vector<int32_t> cur(out_ptr.begin(), out_ptr.end() - 1);
+    for (int64_t m = 1; m < n_mess; ++m) out_edge[(size_t)cur[(size_t)src[m]]++] = (int32_t)m;
+  }
+  struct Step { int32_t t, tree, m, x, y, d; };
+  std::vector<Step> steps;
+  steps.reserve((size_t)n_mess);
+  std::vector<std::vector<int32_t>> reached((size_t)n_nodes);  // edges that have arrived at a node, in order
+  std::vector<int32_t> dep_off((size_t)n_mess, 0), dep_len((size_t)n_mess, 0), dep_tmp, stop_off, stop_len, stop_tmp;
+  std::vector<char> visited((size_t)n_nodes, 0);
+  struct Frame { int32_t x, parent, next; };
+  std::vector<Frame> stack;
+  int32_t max_t = 0;
+  auto emit = [&](int32_t tree, int32_t t, int32_t m, int32_t x, int32_t y, int32_t d) {
+    const std::vector<int32_t>& in = reached[(size_t)x];
+    stop_off.push_back((int32_t)stop_tmp.size());
+    stop_len.push_back((int32_t)in.size());
+    dep_off[(size_t)m] = (int32_t)dep_tmp.size();
+    for (int32_t e : in) {
+      stop_tmp.push_back(e);
+      if (src[e] != y) dep_tmp.push_back(e);
+    }
+    dep_len[(size_t)m] = (int32_t)dep_tmp.size() - dep_off[(size_t)m];
+    steps.push_back(Step{t, tree, m, x, y, d});
+    reached[(size_t)y].push_back(m);
+  };
+  for (int64_t i = 0; i < n_trees; ++i) {
+    const int32_t root = roots[i];
+    if (root < 0 || root >= n_nodes) return JTVAE_E_RANGE;
+    int32_t t = 0;
+    stack.clear();
+    stack.push_back(Frame{root, -1, out_ptr[(size_t)root]});
+    visited[(size_t)root] = 1;
+    while (!stack.empty()) {
+      Frame& f = stack.back();
+      bool went_down = false;
+      while (f.next < out_ptr[(size_t)f.x + 1]) {
+        const int32_t m = out_edge[(size_t)f.next++];
+        const int32_t y = dst[m];
+        if (y == f.parent) continue;
+        if (visited[(size_t)y]) return JTVAE_E_RANGE;  // not a tree
+        visited[(size_t)y] = 1;
+        emit((int32_t)i, t++, m, f.x, y, 1);
+        const int32_t x = f.x;  // f dangles after the push
+        stack.push_back(Frame{y, x, out_ptr[(size_t)y]});
+        went_down = true;
+        break;
+      }
+      if (went_down) continue;
+      const Frame done = stack.back();
+      stack.pop_back();
+      if (!stack.empty()) {  // back to the parent: the edge (done.x -> parent)
+        int32_t back = -1;
+        for (int32_t e = out_ptr[(size_t)done.x]; e < out_ptr[(size_t)done.x + 1]; ++e)
+          if (dst[out_edge[(size_t)e]] == done.parent) { back = out_edge[(size_t)e]; break; }
+        if (back < 0) return JTVAE_E_RANGE;  // the reverse edge is missing
+        emit((int32_t)i, t++, back, done.x, done.parent, 0);
+      }
+    }
+    if (t > max_t) max_t = t;
+  }
+  const int64_t n_steps = (int64_t)steps.size();
+  // dependencies by edge id
+  int64_t nnz = 0;
+  dep_rp[0] = 0;
+  for (int64_t m = 0; m < n_mess; ++m) {
+    if (nnz + dep_len[(size_t)m] > dep_cap) return JTVAE_E_WORKSPACE;
+    for (int32_t k = 0; k < dep_len[(size_t)m]; ++k) dep_col[nnz++] = dep_tmp[(size_t)dep_off[(size_t)m] + k];
+    dep_rp[m + 1] = (int32_t)nnz;
+  }
+  // step rows ordered by (t, tree): counting sort by t, stable in tree order
+  std::vector<int64_t> t_ptr((size_t)max_t + 2, 0);
+  for (const Step& s : steps) ++t_ptr[(size_t)s.t + 1];
+  for (int32_t t = 0; t <= max_t; ++t) t_ptr[(size_t)t + 1] += t_ptr[(size_t)t];
+  std::vector<int64_t> order((size_t)n_steps);
+  for (int64_t k = 0; k < n_steps; ++k) order[(size_t)t_ptr[(size_t)steps[(size_t)k].t]++] = k;
+  int64_t snz = 0, n_down = 0;
+  stop_rp[0] = 0;
+  for (int64_t i = 0; i < n_trees; ++i) {  // word prediction of the roots comes first
+    pred_ctx[i] = (int32_t)i;
+    pred_target[i] = wid[roots[i]];
+  }
+  for (int64_t r = 0; r < n_steps; ++r) {
+    const int64_t k = order[(size_t)r];
+    const Step& s = steps[(size_t)k];
+    if (snz + stop_len[(size_t)k] > stop_cap) return JTVAE_E_WORKSPACE;
+    for (int32_t j = 0; j < stop_len[(size_t)k]; ++j) stop_col[snz++] = stop_tmp[(size_t)stop_off[(size_t)k] + j];
+    stop_rp[r + 1] = (int32_t)snz;
+    stop_word[r] = wid[s.x];
+    stop_ctx[r] = s.tree;
+    stop_target[r] = (float)s.d;
+    if (s.d == 1) {
+      pred_mess[n_down] = s.m;
+      pred_ctx[n_trees + n_down] = s.tree;
+      pred_target[n_trees + n_down] = wid[s.y];
+      ++n_down;
+    }
+  }
+  for (int64_t i = 0; i < n_trees; ++i) {  // the last stop at every root
+    const std::vector<int32_t>& in = reached[(size_t)roots[i]];
+    if (snz + (int64_t)in.size() > stop_cap) return JTVAE_E_WORKSPACE;
+    for (int32_t e : in) stop_col[snz++] = e;
+    const int64_t r = n_steps + i;
+    stop_rp[r + 1] = (int32_t)snz;
+    stop_word[r] = wid[roots[i]];
+    stop_ctx[r] = (int32_t)i;
+    stop_target[r] = 0.f;
+  }
+  counts[0] = n_steps;
+  counts[1] = n_down;
+  counts[2] = nnz;
+  counts[3] = snz;
+  return 0;
+}
+
 }  // extern "C"

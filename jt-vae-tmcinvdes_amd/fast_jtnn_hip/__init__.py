@@ -7,10 +7,11 @@ been built - there is no CPU implementation in the product path.
 """
 from . import _capi  # noqa: F401  (loads the shared library or raises)
 from .jtmpn import JTMPN
+from .jtnn_dec import JTNNDecoder
 from .jtnn_enc import GraphGRU, JTNNEncoder
 from .jtnn_vae import JTNNVAE, JTpropVAE
 from .mpn import MPN
 from .nnutils import create_var, gather_sum, index_select_ND
 
-__all__ = ["MPN", "JTNNEncoder", "GraphGRU", "JTMPN", "JTNNVAE", "JTpropVAE", "create_var", "gather_sum",
-           "index_select_ND"]
+__all__ = ["MPN", "JTNNEncoder", "GraphGRU", "JTMPN", "JTNNDecoder", "JTNNVAE", "JTpropVAE", "create_var",
+           "gather_sum", "index_select_ND"]

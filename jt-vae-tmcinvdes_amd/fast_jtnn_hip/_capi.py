@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Epilogue(C.Structure):
@@ -102,6 +102,8 @@ SIGNATURES = {
     "jtvae_prep_transpose_csr": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_stable_from": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "jtvae_prep_decoder_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
+                                          _vp, _vp, _vp, _vp, _vp]),
     "jtvae_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_csr_gather_sum": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
     "jtvae_slab_sum": (C.c_int, [_vp, _vp, _i32, _sz, _i32, _i32, _i32, _vp]),
@@ -459,3 +461,39 @@ def prep_group_by_key(keys, n_keys):
         raise IndexError("key out of range [0, %d)" % n_keys)
     check(rc, "prep_group_by_key")
     return keyptr, order[:keys.size]
+
+
+def prep_decoder_plan(src, dst, wid, roots):
+    """Decoder trace tables from the junction-tree edges (see jtvae_prep_decoder_plan); returns a dict of arrays."""
+    import numpy as np
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    dst = np.ascontiguousarray(dst, dtype=np.int32)
+    wid = np.ascontiguousarray(wid, dtype=np.int32)
+    roots = np.ascontiguousarray(roots, dtype=np.int32)
+    n_mess, n_nodes, B = src.size, wid.size, roots.size
+    n_dir = n_mess - 1
+    deg = np.bincount(src[1:], minlength=max(n_nodes, 1)).astype(np.int64) if n_dir else np.zeros(1, np.int64)
+    cap = int((deg * deg).sum()) + n_dir + 1
+    rows = n_dir + B
+    a = dict(dep_rp=np.empty(n_mess + 1, np.int32), dep_col=np.empty(cap, np.int32),
+             stop_rp=np.empty(rows + 1, np.int32), stop_col=np.empty(cap, np.int32),
+             stop_word=np.empty(max(rows, 1), np.int32), stop_ctx=np.empty(max(rows, 1), np.int32),
+             stop_target=np.empty(max(rows, 1), np.float32), pred_mess=np.empty(max(n_dir, 1), np.int32),
+             pred_ctx=np.empty(max(rows, 1), np.int32), pred_target=np.empty(max(rows, 1), np.int32))
+    counts = np.zeros(4, np.int64)
+    ptr_of = lambda x: x.__array_interface__["data"][0]  # noqa: E731
+    rc = lib.jtvae_prep_decoder_plan(ptr_of(src), ptr_of(dst), n_mess, ptr_of(wid), n_nodes, ptr_of(roots), B,
+                                     ptr_of(a["dep_rp"]), ptr_of(a["dep_col"]), cap, ptr_of(a["stop_rp"]),
+                                     ptr_of(a["stop_col"]), cap, ptr_of(a["stop_word"]), ptr_of(a["stop_ctx"]),
+                                     ptr_of(a["stop_target"]), ptr_of(a["pred_mess"]), ptr_of(a["pred_ctx"]),
+                                     ptr_of(a["pred_target"]), ptr_of(counts))
+    if rc == E_RANGE:
+        raise IndexError("junction-tree tables do not describe trees (index out of range, cycle or missing "
+                         "reverse edge)")
+    check(rc, "prep_decoder_plan")
+    n_steps, n_down, nnz_dep, nnz_stop = (int(v) for v in counts)
+    n_stop = n_steps + B
+    return dict(dep_rp=a["dep_rp"], dep_col=a["dep_col"][:nnz_dep], stop_rp=a["stop_rp"][:n_stop + 1],
+                stop_col=a["stop_col"][:nnz_stop], stop_word=a["stop_word"][:n_stop], stop_ctx=a["stop_ctx"][:n_stop],
+                stop_target=a["stop_target"][:n_stop], pred_mess=a["pred_mess"][:n_down],
+                pred_ctx=a["pred_ctx"][:B + n_down], pred_target=a["pred_target"][:B + n_down])

@@ -78,23 +78,30 @@ class DecoderPlan:
     pred_target: np.ndarray  # [n_pred] word ids; the first n_trees rows predict the roots from a zero row
 
 
-def decoder_plan(mol_batch) -> DecoderPlan:
+def decoder_plan(mol_batch, mess_dict=None) -> DecoderPlan:
     """Follows fast_jtnn/jtnn_dec.py:59-167: rows are ordered time step by time step, molecules in batch
     order inside a step (the order in which the reference concatenates them), the final stop at every
-    root last.  ``node.neighbors`` is left as it is (the reference clears and rewires it)."""
+    root last.  ``node.neighbors`` is left as it is (the reference clears and rewires it).
+
+    Plain-Python statement of the plan, from the tree objects; messages are numbered in trace order, or
+    with ``mess_dict`` ((x.idx, y.idx) -> id, as JTNNEncoder.tensorize returns it) in the encoder's
+    numbering, which is what ``decoder_plan_from_holder`` produces natively from the tables alone."""
     B = len(mol_batch)
     traces = [dfs_trace(t.nodes[0]) for t in mol_batch]
-    mess_word = [0]
-    dep_lists = [[]]
+    n_mess = 1 + (len(mess_dict) if mess_dict is not None else sum(len(tr) for tr in traces))
+    mess_word = [0] * n_mess
+    dep_lists = [[] for _ in range(n_mess)]
     rows = []  # (t, i, message id, stop list, x word, direction, y word)
     final_lists = []
+    made = 0
     for i, trace in enumerate(traces):
         reached = {}  # node idx -> [(message id, sender idx)] in creation order
         for t, (x, y, d) in enumerate(trace):
-            mid = len(mess_word)
+            made += 1
+            mid = made if mess_dict is None else mess_dict[(x.idx, y.idx)]
             inc = reached.get(x.idx, ())
-            mess_word.append(x.wid)
-            dep_lists.append([m for m, w in inc if w != y.idx])
+            mess_word[mid] = x.wid
+            dep_lists[mid] = [m for m, w in inc if w != y.idx]
             rows.append((t, i, mid, [m for m, _ in inc], x.wid, d, y.wid))
             reached.setdefault(y.idx, []).append((mid, x.idx))
         final_lists.append([m for m, _ in reached.get(mol_batch[i].nodes[0].idx, ())])
@@ -122,6 +129,30 @@ def decoder_plan(mol_batch) -> DecoderPlan:
         pred_mess=np.asarray([r[2] for r in down], dtype=np.int64),
         pred_ctx=np.asarray(list(range(B)) + [r[1] for r in down], dtype=np.int64),
         pred_target=np.asarray([n.wid for n in roots] + [r[6] for r in down], dtype=np.int64))
+
+
+def decoder_plan_from_holder(jtenc_holder) -> DecoderPlan:
+    """The same plan from the junction-tree holder (fnode, fmess, node_graph, mess_graph, scope) that
+    ``JTNNEncoder.tensorize`` built for the batch: the tables hold every tree's nodes, neighbour order and
+    root, so no tree object is touched and the walk runs in the native library."""
+    from . import _capi as K
+
+    fnode, fmess, node_graph, _, scope = jtenc_holder
+    wid = graphprep._to_np(fnode).astype(np.int32)
+    src = graphprep._to_np(fmess).astype(np.int32)
+    ng = graphprep._to_np(node_graph)
+    n_mess = src.shape[0]
+    dst = np.zeros(n_mess, dtype=np.int32)
+    nz = ng != 0
+    dst[ng[nz]] = np.repeat(np.arange(ng.shape[0], dtype=np.int32), nz.sum(axis=1))  # message m arrives at node y
+    roots = np.asarray([st for st, _ in scope], dtype=np.int32)
+    a = K.prep_decoder_plan(src, dst, wid, roots)
+    mess_word = wid[src].astype(np.int64)
+    return DecoderPlan(n_trees=len(roots), n_mess=n_mess, mess_word=mess_word, dep_rp=a["dep_rp"],
+                       dep_col=a["dep_col"], stop_rp=a["stop_rp"], stop_col=a["stop_col"],
+                       stop_word=a["stop_word"].astype(np.int64), stop_ctx=a["stop_ctx"].astype(np.int64),
+                       stop_target=a["stop_target"], pred_mess=a["pred_mess"].astype(np.int64),
+                       pred_ctx=a["pred_ctx"].astype(np.int64), pred_target=a["pred_target"].astype(np.int64))
 
 
 class JTNNDecoder(nn.Module):
@@ -158,25 +189,42 @@ class JTNNDecoder(nn.Module):
                                          self.W_r.bias, self.U_r.weight, None, self.W_h.weight, self.W_h.bias,
                                          prep, torch.is_grad_enabled())
 
-    def forward(self, mol_batch, x_tree_vecs):
+    def forward(self, mol_batch, x_tree_vecs, jtenc_holder=None):
+        """``jtenc_holder``: the junction-tree holder of the same batch, if the caller has it (JTNNVAE.forward
+        does): the trace tables then come from it natively and are kept with it; without it they are built
+        from the tree objects."""
         dev = self.W_z.weight.device
         if dev.type != "cuda":
             raise RuntimeError("fast_jtnn_hip.JTNNDecoder runs on an MI355X only (module is on %s); there is no "
                                "CPU path" % dev)
-        plan = decoder_plan(mol_batch)
+        if jtenc_holder is None:
+            plan = decoder_plan(mol_batch)
+        else:
+            key = jtenc_holder[3]
+            build = lambda: decoder_plan_from_holder(jtenc_holder)  # noqa: E731
+            plan = graphprep.cached_prep(key, ("decoder_plan",), build) if isinstance(key, torch.Tensor) else build()
+            if plan.n_trees != len(mol_batch):
+                raise ValueError("jtenc_holder describes %d trees, the batch has %d" % (plan.n_trees, len(mol_batch)))
         B, H = plan.n_trees, self.hidden_size
         with torch.cuda.device(dev):
-            with graphprep.packed_uploads(dev):
-                # device views are filled when the block ends (one packed copy): nothing may read them inside it
-                idx32 = [graphprep._dev_i32(a, dev) for a in (plan.pred_mess, plan.pred_ctx, plan.pred_target,
-                                                              plan.stop_word, plan.stop_ctx)]
-                stop_csr = graphprep.upload_csr(plan.stop_rp, plan.stop_col, dev)
-                st_rp, st_col = graphprep.transpose_csr(plan.stop_rp, plan.stop_col, plan.n_mess)
-                stop_csr_t = graphprep.upload_csr(st_rp, st_col, dev)
-            pred_mess, pred_ctx, pred_target, stop_word, stop_ctx = (t.long() for t in idx32)
-            stop_target = torch.from_numpy(plan.stop_target).to(dev, non_blocking=True)
-            if plan.n_mess > 1:
-                prep = graphprep.prepare_message_dag(plan.mess_word, plan.dep_rp, plan.dep_col, self.vocab_size, dev)
+            cache = plan.__dict__.setdefault("_device", {})
+            if str(dev) not in cache:  # a plan kept with its holder keeps its device tables too
+                with graphprep.packed_uploads(dev):
+                    # device views are filled when the block ends (one packed copy): nothing may read them inside it
+                    idx32 = [graphprep._dev_i32(a, dev) for a in (plan.pred_mess, plan.pred_ctx, plan.pred_target,
+                                                                  plan.stop_word, plan.stop_ctx)]
+                    stop_csr = graphprep.upload_csr(plan.stop_rp, plan.stop_col, dev)
+                    st_rp, st_col = graphprep.transpose_csr(plan.stop_rp, plan.stop_col, plan.n_mess)
+                    stop_csr_t = graphprep.upload_csr(st_rp, st_col, dev)
+                prep = None
+                if plan.n_mess > 1:
+                    prep = graphprep.prepare_message_dag(plan.mess_word, plan.dep_rp, plan.dep_col, self.vocab_size,
+                                                         dev)
+                cache[str(dev)] = ([t.long() for t in idx32], stop_csr, stop_csr_t,
+                                   torch.from_numpy(np.ascontiguousarray(plan.stop_target)).to(dev), prep)
+            (pred_mess, pred_ctx, pred_target, stop_word, stop_ctx), stop_csr, stop_csr_t, stop_target, prep = \
+                cache[str(dev)]
+            if prep is not None:
                 mess = self.messages(prep)
             else:  # single-node trees only: nothing is ever passed
                 mess = x_tree_vecs.new_zeros((1, H))

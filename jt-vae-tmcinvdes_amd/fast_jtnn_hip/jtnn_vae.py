@@ -229,7 +229,9 @@ class JTNNVAE(nn.Module):
         z_tree_vecs, tree_kl = self.rsample(x_tree_vecs, self.T_mean, self.T_var, e_t)
         z_mol_vecs, mol_kl = self.rsample(x_mol_vecs, self.G_mean, self.G_var, e_g)
         kl_div = tree_kl + mol_kl
-        if hasattr(self, "decoder"):
+        if isinstance(getattr(self, "decoder", None), JTNNDecoder):
+            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs, x_jtenc_holder)
+        elif hasattr(self, "decoder"):
             word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs)
         else:
             word_loss = topo_loss = z_tree_vecs.sum() * 0.0
@@ -272,7 +274,9 @@ class JTpropVAE(JTNNVAE):
         z_tree_vecs, tree_kl = self.rsample(x_tree_vecs, self.T_mean, self.T_var, e_t)
         z_mol_vecs, mol_kl = self.rsample(x_mol_vecs, self.G_mean, self.G_var, e_g)
         kl_div = tree_kl + mol_kl
-        if hasattr(self, "decoder"):
+        if isinstance(getattr(self, "decoder", None), JTNNDecoder):
+            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs, x_jtenc_holder)
+        elif hasattr(self, "decoder"):
             word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs)
         else:
             word_loss = topo_loss = z_tree_vecs.sum() * 0.0

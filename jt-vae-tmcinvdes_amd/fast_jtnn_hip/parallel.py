@@ -22,6 +22,9 @@ import torch
 import torch.distributed as dist
 
 
+_PRESYNC = os.environ.get("JTVAE_ALLREDUCE_PRESYNC", "1") != "0"  # debugging switch for host-staged backends
+
+
 def dist_env() -> Tuple[int, int, int]:
     """(rank, local_rank, world_size) from the launcher's environment; (0, 0, 1) when absent."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
@@ -39,6 +42,36 @@ def init_process_group(backend: str = None, device_index: int = None) -> Tuple[i
             torch.cuda.set_device(local_rank if device_index is None else device_index)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def launch_command(script: str, script_args: Sequence[str], n_procs: int, port: int = None) -> List[str]:
+    """Command line that starts ``script`` as ``n_procs`` ranks of one node, one per GPU."""
+    import sys
+
+    if port is None:
+        import socket
+
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_procs),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(script_args)
+
+
+def self_launch_if_needed(script: str, script_args: Sequence[str], n_gpus: int) -> None:
+    """``python script --gpus N`` with N > 1 and no launcher environment: start the N ranks as child
+    processes (before this process has touched the GPU), pass their output through and exit with their
+    return code.  Returns at once when N == 1 or when already running under a launcher."""
+    import subprocess
+    import sys
+
+    if n_gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes here
+    res = subprocess.run(launch_command(script, script_args, n_gpus), env=env)
+    sys.exit(res.returncode)
 
 
 def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
@@ -95,10 +128,10 @@ class FlatGradBucket:
 
     def all_reduce_mean(self) -> None:
         if dist.is_initialized() and dist.get_world_size() > 1:
-            if self.flat.is_cuda:
-                # The gradients are final only when the backward kernels have run; handing the collective a
-                # buffer with that work still queued stalled a host-staged backend (gloo, two ranks on one GPU).
-                # Waiting here costs one launch latency per step - nothing follows backward that could overlap.
+            if self.flat.is_cuda and dist.get_backend() != "nccl" and _PRESYNC:
+                # A host-staged backend (gloo) copies the bucket to host memory from its own side stream;
+                # draining the launch stream first keeps that copy from queueing behind a whole backward pass.
+                # RCCL enqueues on the launch stream itself and needs no host wait.
                 torch.cuda.current_stream(self.flat.device).synchronize()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())

@@ -117,3 +117,27 @@ def test_compute_once_schedule_covers_every_message_exactly_once():
     # a batch deeper than the iteration count falls back to the iteration-by-iteration form
     shallow_T = int(sf.max()) - 1
     assert G.build_tree_schedule(rp, col, trp, tcol, nm, shallow_T, "cpu", mode="once").mode == "level"
+
+
+def test_native_decoder_plan_equals_the_walk_over_tree_objects():
+    """Trace tables of the teacher-forced decoder: the native walk over the junction-tree holder against the
+    plain-Python walk over the tree objects (encoder numbering of the messages), field by field."""
+    import numpy as np
+
+    from fast_jtnn_hip import synthetic, tensorize as T
+    from fast_jtnn_hip.jtnn_dec import decoder_plan, decoder_plan_from_holder
+
+    for seed, B, atoms in ((1, 1, 30.0), (2, 17, 12.0), (3, 40, 40.0)):
+        trees = synthetic.make_batch(seed, B, vocab_size=50, mean_atoms=atoms)
+        if seed == 2:  # a single-node tree in the middle of the batch
+            trees[5] = synthetic.Tree([synthetic.TreeNode(1, 7)], trees[5].mol)
+            synthetic.set_batch_nodeID(trees)
+        holder, mess_dict = T.jtenc_tensorize(trees)
+        a, b = decoder_plan(trees, mess_dict), decoder_plan_from_holder(holder)
+        assert (a.n_trees, a.n_mess) == (b.n_trees, b.n_mess)
+        for f in ("mess_word", "dep_rp", "dep_col", "stop_rp", "stop_col", "stop_word", "stop_ctx", "stop_target",
+                  "pred_mess", "pred_ctx", "pred_target"):
+            x, y = np.asarray(getattr(a, f)), np.asarray(getattr(b, f))
+            if f == "mess_word":  # entry 0 is the padding message: any valid word
+                x, y = x[1:], y[1:]
+            assert np.array_equal(x, y), (seed, f)
