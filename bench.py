@@ -238,9 +238,6 @@ WHAT = {"train": "forward + backward", "encode": "forward only (no grad)",
 
 
 def main():
-    if os.environ.get("JTVAE_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if the run stalls
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["JTVAE_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -267,6 +264,9 @@ def main():
 
     # N > 1 without a launcher: start the ranks as children before this process touches the GPU
     parallel.self_launch_if_needed(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+    if os.environ.get("JTVAE_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["JTVAE_BENCH_WATCHDOG"]), exit=True)
 
     from fast_jtnn_hip import _capi as K
     from fast_jtnn_hip import trainer
