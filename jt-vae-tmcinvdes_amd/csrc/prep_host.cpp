@@ -54,31 +54,47 @@ int jtvae_prep_transpose_csr(const int32_t* rowptr, const int32_t* col, int64_t 
 
 // sf[m] = 1 when row m reads nothing, else 1 + max over the rows it reads, capped at max(T, 1):
 // the iteration from which message m keeps its value (fast_jtnn/jtnn_enc.py:107-128 recomputes all
-// rows in all T iterations).  T rounds of relaxation also settle graphs with cycles at the cap.
+// rows in all T iterations).  One pass in dependency order (rows become ready when all rows they read
+// are done); rows on or behind a cycle never become ready and sit at the cap, which is where T rounds
+// of the recurrence leave them.
 int jtvae_prep_stable_from(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t T, int32_t* sf) {
   if (n < 0 || T < 0) return JTVAE_E_SHAPE;
   if (!rowptr || !sf) return JTVAE_E_NULL;
   const int32_t cap = T > 1 ? T : 1;
-  for (int64_t m = 0; m < n; ++m) sf[m] = 1;
-  std::vector<int32_t> next((size_t)n);
-  for (int32_t round = 0; round <= cap; ++round) {
-    bool changed = false;
-    for (int64_t m = 0; m < n; ++m) {
-      int32_t v = 1;
-      if (rowptr[m + 1] > rowptr[m]) {
-        int32_t mx = 0;
-        for (int32_t e = rowptr[m]; e < rowptr[m + 1]; ++e) {
-          const int32_t j = col[e];
-          if (j < 0 || j >= n) return JTVAE_E_RANGE;
-          mx = sf[j] > mx ? sf[j] : mx;
-        }
-        v = mx + 1 < cap ? mx + 1 : cap;
-      }
-      next[(size_t)m] = v;
-      changed |= v != sf[m];
+  const int64_t nnz = n > 0 ? rowptr[n] : 0;
+  if (nnz > 0 && !col) return JTVAE_E_NULL;
+  // readers of every row (transposed lists), to release them when a row is done
+  std::vector<int32_t> tptr((size_t)n + 1, 0), tcol((size_t)nnz), pending((size_t)n), ready;
+  for (int64_t e = 0; e < nnz; ++e) {
+    if (col[e] < 0 || col[e] >= n) return JTVAE_E_RANGE;
+    ++tptr[(size_t)col[e] + 1];
+  }
+  for (int64_t j = 0; j < n; ++j) tptr[(size_t)j + 1] += tptr[(size_t)j];
+  {
+    std::vector<int32_t> cur(tptr.begin(), tptr.end() - 1);
+    for (int64_t m = 0; m < n; ++m)
+      for (int32_t e = rowptr[m]; e < rowptr[m + 1]; ++e) tcol[(size_t)cur[(size_t)col[e]]++] = (int32_t)m;
+  }
+  ready.reserve((size_t)n);
+  for (int64_t m = 0; m < n; ++m) {
+    pending[(size_t)m] = rowptr[m + 1] - rowptr[m];
+    sf[m] = cap;  // stays for rows that never become ready
+    if (pending[(size_t)m] == 0) {
+      sf[m] = 1;
+      ready.push_back((int32_t)m);
     }
-    if (!changed) break;
-    std::memcpy(sf, next.data(), sizeof(int32_t) * (size_t)n);
+  }
+  for (size_t head = 0; head < ready.size(); ++head) {
+    const int32_t j = ready[head];
+    for (int32_t e = tptr[(size_t)j]; e < tptr[(size_t)j + 1]; ++e) {
+      const int32_t m = tcol[(size_t)e];
+      if (--pending[(size_t)m] == 0) {
+        int32_t mx = 0;
+        for (int32_t k = rowptr[m]; k < rowptr[m + 1]; ++k) mx = sf[col[k]] > mx ? sf[col[k]] : mx;
+        sf[m] = mx + 1 < cap ? mx + 1 : cap;
+        ready.push_back(m);
+      }
+    }
   }
   return 0;
 }

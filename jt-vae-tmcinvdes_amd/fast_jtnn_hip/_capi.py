@@ -128,11 +128,20 @@ def _load():
             "libjtvae_hip.so is not built (expected at %s); run `make -C jt-vae-tmcinvdes_amd/csrc` "
             "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH
         )
-    lib = C.CDLL(LIB_PATH)
+    # Two handles on the one library.  Kernel launches return in microseconds: they are called WITHOUT giving up
+    # the interpreter lock (PyDLL), because a stepping thread that drops it ~300 times per step has to win it
+    # back each time from a prefetch thread that may be in the middle of Python code.  The host-side index
+    # routines (jtvae_prep_*) run for milliseconds and do release it (CDLL), so prefetch threads overlap them.
+    host, launch = C.CDLL(LIB_PATH), C.PyDLL(LIB_PATH)
+
+    class _Lib:
+        pass
+    lib = _Lib()
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn = getattr(host if name.startswith("jtvae_prep_") else launch, name)  # AttributeError if not exported
         fn.restype = res
         fn.argtypes = args
+        setattr(lib, name, fn)
     got = lib.jtvae_abi_version()
     if got != ABI_VERSION:
         raise ImportError("libjtvae_hip.so ABI %d, host code expects %d" % (got, ABI_VERSION))

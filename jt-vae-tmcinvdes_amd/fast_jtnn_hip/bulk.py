@@ -25,13 +25,15 @@ def shard_path(prefix: str, rank: int, world: int) -> str:
 
 
 def encode_bulk(model, n_items: int, make_holders: Callable[[int, int], Tuple], batch_size: int, prefix: str,
-                what: str = "vectors", rank: int = 0, world: int = 1) -> str:
+                what: str = "vectors", rank: int = 0, world: int = 1, prefetch: int = 2) -> str:
     """Encode items ``[lo, hi)`` of this rank and write them to its shard; returns the shard's path.
 
     ``make_holders(lo, hi)`` returns ``(jtenc_holder, mpn_holder)`` of items ``lo..hi-1`` (the
     reference's ``tensorize(..., assm=False)`` output, fast_jtnn/datautils.py:140-163).
     ``what``: ``"vectors"`` stores ``cat(tree_vecs, mol_vecs)`` ``[n, 2H]`` (what ``encode_from_smiles``
     returns), ``"mean"`` the latent means ``[n, latent]`` of ``encode_latent``.
+    ``prefetch``: batches that a background thread tensorizes, prepares and uploads ahead of the encoder
+    (0: everything in the calling thread).
     """
     if what not in ("vectors", "mean"):
         raise ValueError("what must be 'vectors' or 'mean'")
@@ -55,13 +57,22 @@ def encode_bulk(model, n_items: int, make_holders: Callable[[int, int], Tuple], 
             out[row:row + n] = staging[i][:n].numpy()
             pending = None
 
+    def holders():
+        for b_lo in range(lo, hi, batch_size):
+            b_hi = min(b_lo + batch_size, hi)
+            yield (b_lo, b_hi) + tuple(make_holders(b_lo, b_hi))
+
+    source = holders()
+    if prefetch > 0:
+        from .prefetch import Prefetcher, warm_encoder_holders
+
+        source = Prefetcher(source, lambda it: warm_encoder_holders(model, it[2], it[3], train=False), dev,
+                            depth=prefetch)
     was_training = model.training
     model.eval()
     try:
         with torch.no_grad():
-            for k, b_lo in enumerate(range(lo, hi, batch_size)):
-                b_hi = min(b_lo + batch_size, hi)
-                jt, mp = make_holders(b_lo, b_hi)
+            for k, (b_lo, b_hi, jt, mp) in enumerate(source):
                 if what == "vectors":
                     res = model.encode_vectors(jt, mp)
                 else:
@@ -79,6 +90,8 @@ def encode_bulk(model, n_items: int, make_holders: Callable[[int, int], Tuple], 
             drain()
     finally:
         model.train(was_training)
+        if prefetch > 0:
+            source.close()
     out.flush()
     del out
     return path

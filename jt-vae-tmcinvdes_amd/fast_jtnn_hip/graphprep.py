@@ -19,6 +19,7 @@ their numpy statements, kept as the checkers of the native ones.
 """
 from __future__ import annotations
 
+import threading
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
@@ -127,7 +128,7 @@ class _UploadBatch:
         if not self.chunks or self.chunks[-1][2] + n4 > self.chunks[-1][0].numel():
             size = max(self.CHUNK, n4)
             self.chunks.append([torch.empty(size, dtype=torch.int32, pin_memory=True),
-                                torch.empty(size, dtype=torch.int32, device=self.device), 0])
+                                _new_device_tensor(torch.empty(size, dtype=torch.int32, device=self.device)), 0])
         host, dev, used = self.chunks[-1]
         host.numpy()[used:used + n] = a.reshape(-1)
         self.chunks[-1][2] = used + n4
@@ -140,7 +141,37 @@ class _UploadBatch:
         self.chunks = []
 
 
-_ACTIVE_UPLOAD = None
+class _ThreadState(threading.local):
+    upload = None  # the _UploadBatch of the innermost packed_uploads block of this thread
+    consumer_stream = None  # set by a prefetch thread: the stream whose kernels will read what it uploads
+
+
+_TLS = _ThreadState()
+
+
+def _new_device_tensor(t: torch.Tensor) -> torch.Tensor:
+    """Every device tensor this module allocates passes through here.  A prefetch thread allocates and fills
+    on its own copy stream; telling the allocator which stream will read the tensor keeps the memory from
+    being handed out again while those reads are still queued."""
+    if _TLS.consumer_stream is not None and t.is_cuda:
+        t.record_stream(_TLS.consumer_stream)
+    return t
+
+
+class consumer_stream:
+    """``with consumer_stream(s):`` - device tensors created inside (on this thread) will be read on ``s``."""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev = _TLS.consumer_stream
+        _TLS.consumer_stream = self.stream
+        return self
+
+    def __exit__(self, *exc):
+        _TLS.consumer_stream = self.prev
+        return False
 
 
 class packed_uploads:
@@ -150,16 +181,14 @@ class packed_uploads:
         self.device = torch.device(device)
 
     def __enter__(self):
-        global _ACTIVE_UPLOAD
-        self.prev = _ACTIVE_UPLOAD
-        _ACTIVE_UPLOAD = _UploadBatch(self.device) if self.device.type == "cuda" else None
+        self.prev = _TLS.upload
+        _TLS.upload = _UploadBatch(self.device) if self.device.type == "cuda" else None
         return self
 
     def __exit__(self, *exc):
-        global _ACTIVE_UPLOAD
-        if _ACTIVE_UPLOAD is not None:
-            _ACTIVE_UPLOAD.flush()
-        _ACTIVE_UPLOAD = self.prev
+        if _TLS.upload is not None:
+            _TLS.upload.flush()
+        _TLS.upload = self.prev
         return False
 
 
@@ -167,9 +196,9 @@ def _dev_i32(a: np.ndarray, device) -> torch.Tensor:
     if a.size and int(a.max()) >= 2 ** 31:
         raise OverflowError("index exceeds int32")
     a = np.ascontiguousarray(a, dtype=np.int32)
-    if _ACTIVE_UPLOAD is not None and _ACTIVE_UPLOAD.device == torch.device(device):
-        return _ACTIVE_UPLOAD.add(a)
-    return torch.from_numpy(a).to(device)
+    if _TLS.upload is not None and _TLS.upload.device == torch.device(device):
+        return _TLS.upload.add(a)
+    return _new_device_tensor(torch.from_numpy(a).to(device))
 
 
 def upload_csr(rowptr: np.ndarray, col: np.ndarray, device) -> DeviceCSR:
@@ -182,10 +211,10 @@ def _upload_features(x: np.ndarray, device) -> torch.Tensor:
     device, so the host only hands over the array it already has."""
     n, f = x.shape
     fp = (f + 3) // 4 * 4
-    src = torch.from_numpy(np.ascontiguousarray(x)).to(device)
+    src = _new_device_tensor(torch.from_numpy(np.ascontiguousarray(x)).to(device, non_blocking=True))
     if fp == f:
         return src
-    out = torch.zeros((n, fp), dtype=torch.float32, device=device)
+    out = _new_device_tensor(torch.zeros((n, fp), dtype=torch.float32, device=device))
     out[:, :f] = src
     return out
 
@@ -229,14 +258,26 @@ class GraphMPNPrep:
     n_seg: int
     b_tree_nnz: int = 0  # bgraph / agraph entries that point at tree-message rows
     a_tree_nnz: int = 0
+    host: dict = None  # CSR arrays kept for the transposes when they were not built (inference)
+
+    def ensure_transposes(self):
+        """The transposed adjacency is only read by the backward pass; a holder prepared for inference gets it
+        on its first use under gradient mode."""
+        if self.bcsr_t is None:
+            h, dev = self.host, self.fatoms.device
+            n_src = self.n_tree + self.n_bonds
+            with packed_uploads(dev):
+                self.bcsr_t = upload_csr(*transpose_csr(h["b_rp"], h["b_col"], n_src), dev)
+                self.acsr_t = upload_csr(*transpose_csr(h["a_rp"], h["a_col"], n_src), dev)
+        return self
 
 
-def prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
+def prepare_mpn(holder, device, n_tree: int = 0, train: bool = True) -> GraphMPNPrep:
     with packed_uploads(device):
-        return _prepare_mpn(holder, device, n_tree)
+        return _prepare_mpn(holder, device, n_tree, train)
 
 
-def _prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
+def _prepare_mpn(holder, device, n_tree: int = 0, train: bool = True) -> GraphMPNPrep:
     fatoms, fbonds, agraph, bgraph, scope = holder
     fa, fb = np.asarray(_to_np(fatoms), dtype=np.float32), np.asarray(_to_np(fbonds), dtype=np.float32)
     ag, bg = _to_np(agraph), _to_np(bgraph)
@@ -247,16 +288,17 @@ def _prepare_mpn(holder, device, n_tree: int = 0) -> GraphMPNPrep:
     n_src = n_tree + nb
     b_rp, b_col = padded_to_csr(bg, n_src)
     a_rp, a_col = padded_to_csr(ag, n_src)
-    bt_rp, bt_col = transpose_csr(b_rp, b_col, n_src)
-    at_rp, at_col = transpose_csr(a_rp, a_col, n_src)
     seg, seg_of = scope_arrays(scope, na)
     return GraphMPNPrep(
         fatoms=_upload_features(fa, device),
         fbonds=_upload_features(fb, device),
         atom_fdim=fa.shape[1], bond_in_fdim=fb.shape[1],
         n_atoms=na, n_bonds=nb, n_tree=n_tree,
-        bcsr=upload_csr(b_rp, b_col, device), bcsr_t=upload_csr(bt_rp, bt_col, device),
-        acsr=upload_csr(a_rp, a_col, device), acsr_t=upload_csr(at_rp, at_col, device),
+        bcsr=upload_csr(b_rp, b_col, device),
+        bcsr_t=upload_csr(*transpose_csr(b_rp, b_col, n_src), device) if train else None,
+        acsr=upload_csr(a_rp, a_col, device),
+        acsr_t=upload_csr(*transpose_csr(a_rp, a_col, n_src), device) if train else None,
+        host=None if train else dict(b_rp=b_rp, b_col=b_col, a_rp=a_rp, a_col=a_col),
         seg=_dev_i32(seg.reshape(-1), device).view(-1, 2) if seg.size else torch.zeros((0, 2), dtype=torch.int32, device=device),
         seg_of=_dev_i32(seg_of, device) if na else torch.zeros(1, dtype=torch.int32, device=device),
         n_seg=int(seg.shape[0]),
@@ -510,39 +552,55 @@ def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False, 
     mode = mode or ("dense" if dense else "once")
     if mode not in ("dense", "level", "once"):
         raise ValueError("unknown schedule mode %r" % (mode,))
-    if mode == "once":
-        deep = T < 1 or (nm > 0 and int(K.prep_stable_from(m_rp, m_col, T + 1).max()) > T)
-        if deep:
-            mode = "level"
+    sf_true = K.prep_stable_from(m_rp, m_col, 2 ** 30) if (nm > 0 and mode != "dense") else None  # uncapped
+    if mode == "once" and (T < 1 or (nm > 0 and int(sf_true.max()) > T)):
+        mode = "level"  # a tree deeper than the iteration count: follow the truncated recurrence
     with packed_uploads(device):
-        return _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode)
+        return _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode, sf_true)
 
 
-def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode) -> TreeSchedule:
+def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode, sf_true=None) -> TreeSchedule:
     dense = mode == "dense"
     once = mode == "once"
     deg = np.diff(m_rp)
     tdeg = np.diff(mt_rp)
-    if dense or T < 1:
+    if dense or T < 1 or sf_true is None:
         sf = np.full(nm, max(T, 1), dtype=np.int64)
     else:
-        sf = K.prep_stable_from(m_rp, m_col, T).astype(np.int64)
+        sf = np.minimum(sf_true.astype(np.int64), max(T, 1))
     F, U = [], []
     total_nnz = int(m_col.shape[0])
+    if once:
+        # messages grouped by the iteration in which they settle, message order inside a group: iteration t
+        # updates group t + 1 and needs the U_r products of group t's members that somebody reads
+        keyptr, order = K.prep_group_by_key(sf.astype(np.int32), max(T, 1) + 1)
+        order = order.astype(np.int64)
+        order_dev = _dev_i32(order, device) if nm else None
+        read = tdeg[order] > 0
+        u_rows = order[read]
+        u_ptr = np.concatenate([[0], np.cumsum(read)])[keyptr]  # start of every group inside u_rows
+        u_dev = _dev_i32(u_rows, device) if u_rows.size else None
+        nnz_ptr = np.concatenate([[0], np.cumsum(deg[order])])
     for t in range(T):
         if dense or t == 0:
             F.append(RowList(None, nm, total_nnz))
+        elif once:
+            a, b = int(keyptr[t + 1]), int(keyptr[t + 2])
+            F.append(RowList(order_dev[a:b] if b > a else None, b - a, int(nnz_ptr[b] - nnz_ptr[a])))
         else:
-            r = np.flatnonzero(sf == t + 1) if once else np.flatnonzero(sf > t)
+            r = np.flatnonzero(sf > t)
             F.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size), int(deg[r].sum())))
         if t == 0:
             U.append(RowList(None, 0))
         elif dense:
             U.append(RowList(None, nm))
+        elif once:
+            a, b = int(u_ptr[t]), int(u_ptr[t + 1])
+            U.append(RowList(u_dev[a:b] if b > a else None, b - a))
         else:
             # messages whose U_r product is read in this iteration and not yet available: those that took
             # their current value in iteration t-1 and have readers
-            r = np.flatnonzero(((sf == t) if once else (sf >= t)) & (tdeg > 0))
+            r = np.flatnonzero((sf >= t) & (tdeg > 0))
             U.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size)))
     host = dict(m_rp=np.asarray(m_rp, dtype=np.int64), m_col=np.asarray(m_col, dtype=np.int64),
                 mt_rp=np.asarray(mt_rp, dtype=np.int64), mt_col=np.asarray(mt_col, dtype=np.int64), sf=sf, nm=nm,
@@ -636,7 +694,7 @@ def _build_backward_schedule_once(sched: TreeSchedule, seeds: Optional[np.ndarra
     one = np.zeros(1, dtype=np.int64)
     return BackwardSchedule(
         E=El, J=Jl, offE=offE, offJ=offJ, nE=nE, nJ=nJ,
-        active=torch.from_numpy(act.astype(np.int64)).to(device),
+        active=_new_device_tensor(torch.from_numpy(act.astype(np.int64)).to(device)),
         zx=_dev_i32(zx if zx.size else one, device), zy=_dev_i32(zy if zy.size else one, device), n_z=int(zx.size),
         ux=_dev_i32(ux if ux.size else one, device), uy=_dev_i32(uy if uy.size else one, device), n_u=int(ux.size),
         key_pieces=kp, key=kc, once=True, n_dep=n_dep)
@@ -718,7 +776,7 @@ def _build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], w
     one = np.zeros(1, dtype=np.int64)
     return BackwardSchedule(
         E=El, J=Jl, offE=offE, offJ=offJ, nE=nE, nJ=nJ,
-        active=torch.from_numpy(active).to(device) if use_mask else None,
+        active=_new_device_tensor(torch.from_numpy(active).to(device)) if use_mask else None,
         zx=_dev_i32(zx if zx.size else one, device), zy=_dev_i32(zy if zy.size else one, device), n_z=int(zx.size),
         ux=_dev_i32(ux if ux.size else one, device), uy=_dev_i32(uy if uy.size else one, device), n_u=int(ux.size),
         key_pieces=kp, key=kc)

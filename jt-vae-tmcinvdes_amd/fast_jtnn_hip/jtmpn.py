@@ -47,7 +47,8 @@ class JTMPN(nn.Module):
             raise ValueError("tree_message is on %s, module on %s" % (tree_message.device, device))
         n_tree = int(tree_message.shape[0])
         key = bgraph if isinstance(bgraph, torch.Tensor) else None
-        build = lambda: graphprep.prepare_mpn((fatoms, fbonds, agraph, bgraph, scope), device, n_tree)  # noqa: E731
+        build = lambda: graphprep.prepare_mpn((fatoms, fbonds, agraph, bgraph, scope), device, n_tree,
+                                                torch.is_grad_enabled())  # noqa: E731
         prep = build() if key is None else graphprep.cached_prep(key, ("jtmpn", str(device), n_tree), build)
         if prep.bond_in_fdim != self.W_i.in_features or prep.atom_fdim + self.hidden_size != self.W_o.in_features:
             raise ValueError("feature widths %d/%d do not match W_i/W_o" % (prep.bond_in_fdim, prep.atom_fdim))

@@ -155,6 +155,7 @@ class _GraphMPNFunction(torch.autograd.Function):
         K.segment_mean(out.data_ptr(), ah.data_ptr(), P.seg.data_ptr(), P.n_seg, H, ld, n_rows=NA)
 
         if train:
+            P.ensure_transposes()
             ctx.prep, ctx.depth, ctx.H, ctx.ld = P, depth, H, ld
             ctx.saved = (msgs, neis, anei, ah, W_h, W_o_w)
             ctx.W_i_shape, ctx.W_o_shape = tuple(W_i.shape), tuple(W_o_w.shape)
@@ -219,9 +220,9 @@ class _GraphMPNFunction(torch.autograd.Function):
         return dW_i, dW_h, dW_o, db_o, dtree_out, None, None, None
 
 
-def _holder_prep(fatoms, fbonds, agraph, bgraph, scope, device, n_tree):
+def _holder_prep(fatoms, fbonds, agraph, bgraph, scope, device, n_tree, train=True):
     key = bgraph if isinstance(bgraph, torch.Tensor) else None
-    build = lambda: graphprep.prepare_mpn((fatoms, fbonds, agraph, bgraph, scope), device, n_tree)  # noqa: E731
+    build = lambda: graphprep.prepare_mpn((fatoms, fbonds, agraph, bgraph, scope), device, n_tree, train)  # noqa: E731
     if key is None:
         return build()
     return graphprep.cached_prep(key, ("mpn", str(device), n_tree), build)
@@ -243,7 +244,7 @@ class MPN(nn.Module):
                                "CPU path" % device)
         if self.depth < 1:
             raise ValueError("depth must be >= 1")
-        prep = _holder_prep(fatoms, fbonds, agraph, bgraph, scope, device, 0)
+        prep = _holder_prep(fatoms, fbonds, agraph, bgraph, scope, device, 0, torch.is_grad_enabled())
         if prep.bond_in_fdim != self.W_i.in_features or prep.atom_fdim + self.hidden_size != self.W_o.in_features:
             raise ValueError("feature widths %d/%d do not match W_i/W_o" % (prep.bond_in_fdim, prep.atom_fdim))
         with torch.cuda.device(device):

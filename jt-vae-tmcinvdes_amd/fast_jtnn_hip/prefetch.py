@@ -1,0 +1,125 @@
+"""Holder preparation off the critical path.
+
+The reference builds the index tables of a batch on the host and copies them to the GPU inside every
+``forward`` (``create_var``: fast_jtnn/nnutils.py:6-10, called from fast_jtnn/mpn.py:82-85,
+jtnn_enc.py:21-25, jtmpn.py:84-87), so the GPU waits for the host once per step.  Here the device-side
+form of a batch (CSR adjacency and its transpose, tree-GRU schedules for forward and backward, decoder
+trace tables, padded feature matrices) is built and uploaded by a background thread on its own copy
+stream while the GPU runs the previous batch; the modules find it attached to the holder tensors.
+
+    for x_batch in Prefetcher(loader, lambda b: warm_training_batch(model, b), device):
+        trainer.step(x_batch)
+"""
+from __future__ import annotations
+
+import queue
+import threading
+
+import torch
+
+from . import graphprep
+
+_END = object()
+
+
+def warm_encoder_holders(model, jtenc_holder, mpn_holder, train=True, messages_used=False):
+    """Builds (and attaches to the holder tensors) what ``model.encode`` will look up: the same builders under
+    the same keys as JTNNEncoder.forward / MPN.forward use."""
+    from . import jtnn_enc
+    from .mpn import _holder_prep
+
+    dev = model.mpn.W_h.weight.device
+    V = model.jtnn.embedding.weight.shape[0]
+    build = lambda: graphprep.prepare_tree(jtenc_holder, dev, V)  # noqa: E731
+    prep = graphprep.cached_prep(jtenc_holder[3], ("tree", str(dev), V), build)
+    sched = graphprep.tree_schedule(prep, model.jtnn.depth, mode=jtnn_enc.SCHEDULE)
+    if train:
+        graphprep.backward_schedule(prep, sched, all_messages=messages_used)
+    _holder_prep(*mpn_holder, dev, 0, train)
+    return prep
+
+
+def warm_training_batch(model, x_batch):
+    """The whole x_batch of JTNNVAE.forward / JTpropVAE.forward: encoders, candidate graphs, decoder traces."""
+    from .jtnn_dec import JTNNDecoder, decoder_plan_from_holder
+
+    if len(x_batch) == 5:
+        _, _, jt, mp, (cj, _) = x_batch
+    else:
+        _, jt, mp, (cj, _) = x_batch
+    dev = model.mpn.W_h.weight.device
+    warm_encoder_holders(model, jt, mp, train=True, messages_used=True)
+    n_tree = int(jt[3].shape[0])
+    build = lambda: graphprep.prepare_mpn(cj, dev, n_tree)  # noqa: E731
+    graphprep.cached_prep(cj[3], ("jtmpn", str(dev), n_tree), build)
+    if isinstance(getattr(model, "decoder", None), JTNNDecoder):
+        graphprep.cached_prep(jt[3], ("decoder_plan",), lambda: decoder_plan_from_holder(jt))
+    return x_batch
+
+
+class Prefetcher:
+    """Iterates ``source`` in order, with ``prepare(item)`` run up to ``depth`` items ahead by ``workers``
+    background threads.
+
+    A feeder thread walks ``source`` (so the loader's own work is off the stepping thread too) and hands every
+    item to the pool; ``prepare`` runs under the worker's own copy stream, so its host-to-device copies overlap
+    the kernels of the batch in flight; the consumer's stream waits for them (an event per item) when the item
+    is handed over, and the allocator is told that the consumer's stream reads what was uploaded.  An exception
+    raised by the source or by ``prepare`` is re-raised in the consumer at the position of the item that caused
+    it.
+    """
+
+    def __init__(self, source, prepare, device, depth: int = 4, workers: int = 3):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Prefetcher uploads to an MI355X; got device %s" % self.device)
+        self.source, self.prepare = source, prepare
+        self.q = queue.Queue(maxsize=max(1, depth))
+        self.consumer = torch.cuda.current_stream(self.device)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers), thread_name_prefix="jtvae-prep")
+        self.tls = threading.local()
+        self.stop = False
+        self.thread = threading.Thread(target=self._feed, name="jtvae-prefetch", daemon=True)
+        self.thread.start()
+
+    def _prepare(self, item):
+        if getattr(self.tls, "stream", None) is None:
+            torch.cuda.set_device(self.device)
+            self.tls.stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self.tls.stream), graphprep.consumer_stream(self.consumer):
+            self.prepare(item)  # attaches its results to the item's holder tensors
+            ev = torch.cuda.Event()
+            ev.record(self.tls.stream)
+        return ev
+
+    def _feed(self):
+        try:
+            for item in self.source:
+                if self.stop:
+                    break
+                self.q.put((item, self.pool.submit(self._prepare, item), None))
+            self.q.put((None, None, _END))
+        except BaseException as e:  # handed to the consumer
+            self.q.put((None, None, e))
+
+    def __iter__(self):
+        while True:
+            item, fut, tag = self.q.get()
+            if tag is _END:
+                return
+            if tag is not None:
+                raise tag
+            torch.cuda.current_stream(self.device).wait_event(fut.result())
+            yield item
+
+    def close(self):
+        self.stop = True
+        while self.thread.is_alive():
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                pass
+            self.thread.join(timeout=0.05)
+        self.pool.shutdown(wait=True)

@@ -132,9 +132,15 @@ def main(argv=None):
     tr = trainer.Trainer(model, sched, save_dir=args.save_dir, conditional=args.conditional,
                          total_step=args.load_epoch)
     torch.manual_seed(1234 + rank)  # every rank draws its own rsample noise
+    from fast_jtnn_hip.prefetch import Prefetcher, warm_training_batch
+
     for epoch in range(args.epoch):
-        for batch in synthetic_batches(args.train, V, args.batch_size, rank, world, epoch, args.conditional):
+        # the next batch is tensorized, prepared and uploaded by a background thread while this one steps
+        loader = Prefetcher(synthetic_batches(args.train, V, args.batch_size, rank, world, epoch, args.conditional),
+                            lambda b: warm_training_batch(model, b), device)
+        for batch in loader:
             tr.step(batch)
+        loader.close()
     tr.save("model.epoch-%d" % tr.total_step)  # vae_train.py:146
     if world > 1:
         torch.distributed.barrier()
