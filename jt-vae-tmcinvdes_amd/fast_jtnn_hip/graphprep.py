@@ -445,6 +445,53 @@ def prepare_message_dag(word_of_mess: np.ndarray, dep_rp: np.ndarray, dep_col: n
             schedules={})
 
 
+def split_deep_trees(holder, T: int):
+    """Trees whose messages settle within T iterations can be computed once per message; a tree with a longer
+    chain (its truncated recurrence differs from the fixed point, fast_jtnn/jtnn_enc.py:111) needs the
+    iteration-by-iteration schedule with per-iteration state.  Returns None when no tree of the holder is that
+    deep, else ((shallow holder, tree ids, message ids), (deep holder, tree ids, message ids)): two holders in
+    the reference's layout over disjoint sets of trees, with the positions of their trees and messages in the
+    original batch - so that one deep tree does not drag a whole batch onto the slow, memory-hungry schedule."""
+    fnode, fmess, node_graph, mess_graph, scope = holder
+    fn, fm = _to_np(fnode).astype(np.int64), _to_np(fmess).astype(np.int64)
+    ng, mg = _to_np(node_graph).astype(np.int64), _to_np(mess_graph).astype(np.int64)
+    nm = fm.shape[0]
+    if nm <= 1 or T < 1:
+        return None
+    m_rp, m_col = padded_to_csr(mg, nm)
+    sf = K.prep_stable_from(m_rp, m_col, 2 ** 30)
+    if int(sf.max()) <= T:
+        return None
+    sc = np.asarray(scope, dtype=np.int64).reshape(-1, 2)
+    tree_of_node = np.repeat(np.arange(sc.shape[0], dtype=np.int64), sc[:, 1])
+    if tree_of_node.shape[0] != fn.shape[0] or not np.array_equal(sc[:, 0], np.concatenate([[0], np.cumsum(sc[:, 1])[:-1]])):
+        return None  # not the tensorizer's contiguous layout: leave the batch whole
+    tree_of_mess = tree_of_node[fm]
+    deep = np.zeros(sc.shape[0], dtype=bool)
+    deep[np.unique(tree_of_mess[1:][sf[1:] > T])] = True
+    if deep.all():
+        return None
+
+    def part(mask):
+        trees = np.flatnonzero(mask)
+        keep_node = mask[tree_of_node]
+        keep_mess = mask[tree_of_mess]
+        keep_mess[0] = False
+        mess_ids = np.flatnonzero(keep_mess)
+        node_new = np.cumsum(keep_node) - 1
+        mess_new = np.zeros(nm, dtype=np.int64)
+        mess_new[mess_ids] = np.arange(1, mess_ids.shape[0] + 1)
+        fm_new = np.concatenate([[0], node_new[fm[mess_ids]]])
+        mg_new = np.concatenate([np.zeros((1, mg.shape[1]), dtype=np.int64), mess_new[mg[mess_ids]]], axis=0)
+        lens = sc[trees, 1]
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+        sub = (torch.from_numpy(fn[keep_node]), torch.from_numpy(fm_new), torch.from_numpy(mess_new[ng[keep_node]]),
+               torch.from_numpy(mg_new), [(int(a), int(b)) for a, b in zip(starts, lens)])
+        return sub, torch.from_numpy(trees), torch.from_numpy(mess_ids)
+
+    return part(~deep), part(deep)
+
+
 def tree_schedule(prep: TreePrep, T: int, dense: bool = False, mode: str = None) -> TreeSchedule:
     mode = mode or ("dense" if dense else "once")
     key = (T, mode)

@@ -486,6 +486,28 @@ class JTNNEncoder(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("fast_jtnn_hip.JTNNEncoder runs on an MI355X only (module is on %s); there is "
                                "no CPU path" % dev)
+        holder = (fnode, fmess, node_graph, mess_graph, scope)
+        if SCHEDULE == "once":
+            # trees deeper than the iteration count take the iteration-by-iteration schedule on their own
+            key = mess_graph if isinstance(mess_graph, torch.Tensor) else None
+            build = lambda: graphprep.split_deep_trees(holder, self.depth)  # noqa: E731
+            split = build() if key is None else graphprep.cached_prep(key, ("deep_split", self.depth), build)
+            if split is not None:
+                return self._forward_split(split, len(scope), int(mess_graph.shape[0]), dev)
+        return self._forward_holder(holder, dev)
+
+    def _forward_split(self, split, n_trees, n_mess, dev):
+        H = self.hidden_size
+        tree_vecs = torch.zeros((n_trees, H), dtype=torch.float32, device=dev)
+        messages = torch.zeros((n_mess, H), dtype=torch.float32, device=dev)  # row 0: the padding message
+        for sub, tree_ids, mess_ids in split:
+            tv, ms = self._forward_holder(sub, dev)
+            tree_vecs = tree_vecs.index_copy(0, tree_ids.to(dev), tv)
+            messages = messages.index_copy(0, mess_ids.to(dev), ms[1:])
+        return tree_vecs, messages
+
+    def _forward_holder(self, holder, dev):
+        fnode, fmess, node_graph, mess_graph, scope = holder
         V = self.embedding.weight.shape[0]
         key = mess_graph if isinstance(mess_graph, torch.Tensor) else None
         build = lambda: graphprep.prepare_tree((fnode, fmess, node_graph, mess_graph, scope), dev, V)  # noqa: E731

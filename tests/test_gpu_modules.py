@@ -482,3 +482,51 @@ def test_standalone_graph_gru_matches_oracle():
     assert float(got[0].abs().max()) == 0.0
     with pytest.raises(RuntimeError):
         hip(torch.zeros(NM, H), x, mess_graph)  # gradients enabled: train through JTNNEncoder instead
+
+
+def test_one_deep_tree_in_a_batch_keeps_the_batch_on_the_compute_once_schedule():
+    """A chain of 30 clusters (deeper than depthT = 20) among 96 ordinary trees: outputs and gradients equal
+    the dense schedule's and the CPU oracle's, and the step does not allocate per-iteration state for the
+    whole batch (what the level schedule would need: 7 x [T, NM, ld] floats)."""
+    import fast_jtnn_hip.jtnn_enc as enc
+    from fast_jtnn_hip import JTNNEncoder, synthetic, tensorize as T
+    from oracle.ref_encoder import OracleJTNNEncoder
+
+    V, H, depth = 40, 450, 20
+    trees = synthetic.make_batch(6, 96, vocab_size=V, mean_atoms=40.0)
+    chain = [synthetic.TreeNode(i + 1, (7 * i) % V) for i in range(30)]
+    for a, b in zip(chain[:-1], chain[1:]):
+        a.neighbors.append(b); b.neighbors.append(a)
+    trees.insert(50, synthetic.Tree(chain, trees[0].mol))
+    synthetic.set_batch_nodeID(trees)
+    jt, _ = T.jtenc_tensorize(trees)
+    NM = jt[3].shape[0]
+    out = {}
+    for mode in ("once", "dense"):
+        enc.SCHEDULE = mode
+        try:
+            m = JTNNEncoder(H, depth, torch.nn.Embedding(V, H)).cuda()
+            synthetic.fill_params(list(m.named_parameters()), 4, 0.1)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            tv, ms = m(*jt)
+            (tv.sum() + (ms * ms).sum()).backward()
+            torch.cuda.synchronize()
+            out[mode] = (tv.detach().cpu().numpy(), ms.detach().cpu().numpy(),
+                         {n: p.grad.cpu().numpy() for n, p in m.named_parameters()},
+                         torch.cuda.max_memory_allocated() - base)
+        finally:
+            enc.SCHEDULE = "once"
+    assert rel_err(out["once"][0], out["dense"][0]) < 2e-6 and rel_err(out["once"][1], out["dense"][1]) < 2e-6
+    for n in out["dense"][2]:
+        assert fro_err(out["once"][2][n], out["dense"][2][n]) < 1e-5, n
+    slab_bytes = 7 * depth * NM * 452 * 4
+    assert out["once"][3] < 0.25 * slab_bytes, (out["once"][3], slab_bytes)
+    ora = OracleJTNNEncoder(H, depth, torch.nn.Embedding(V, H))
+    synthetic.fill_params(list(ora.named_parameters()), 4, 0.1)
+    tvo, mso = ora(*jt)
+    assert rel_err(out["once"][0], tvo.detach().numpy()) < RTOL and rel_err(out["once"][1], mso.detach().numpy()) < RTOL
+    (tvo.sum() + (mso * mso).sum()).backward()
+    for n, q in ora.named_parameters():
+        assert fro_err(out["once"][2][n], q.grad.numpy()) < RTOL, n

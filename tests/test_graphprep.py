@@ -141,3 +141,34 @@ def test_native_decoder_plan_equals_the_walk_over_tree_objects():
             if f == "mess_word":  # entry 0 is the padding message: any valid word
                 x, y = x[1:], y[1:]
             assert np.array_equal(x, y), (seed, f)
+
+
+def test_deep_trees_are_split_off_the_batch():
+    """One chain longer than the iteration count among ordinary trees: the holder splits into two valid
+    holders whose tables are those of tensorizing the two groups on their own."""
+    import numpy as np
+
+    from fast_jtnn_hip import graphprep, synthetic, tensorize as T
+
+    trees = synthetic.make_batch(2, 9, vocab_size=30, mean_atoms=14.0)
+    chain = [synthetic.TreeNode(i + 1, i % 30) for i in range(12)]
+    for a, b in zip(chain[:-1], chain[1:]):
+        a.neighbors.append(b); b.neighbors.append(a)
+    trees.insert(4, synthetic.Tree(chain, trees[0].mol))
+    synthetic.set_batch_nodeID(trees)
+    holder, _ = T.jtenc_tensorize(trees)
+    assert graphprep.split_deep_trees(holder, 20) is None  # everything settles within 20 iterations
+    (sh, sh_trees, sh_mess), (dp, dp_trees, dp_mess) = graphprep.split_deep_trees(holder, 6)
+    assert dp_trees.tolist() == [4] and sh_trees.tolist() == [0, 1, 2, 3, 5, 6, 7, 8, 9]
+    assert sorted(sh_mess.tolist() + dp_mess.tolist()) == list(range(1, holder[1].shape[0]))
+    for sub, ids in ((sh, sh_trees), (dp, dp_trees)):
+        part = [trees[i] for i in ids.tolist()]
+        synthetic.set_batch_nodeID(part)
+        want, _ = T.jtenc_tensorize(part)
+        assert np.array_equal(sub[0].numpy(), want[0].numpy()) and np.array_equal(sub[1].numpy(), want[1].numpy())
+        k = want[2].shape[1]
+        assert np.array_equal(sub[2].numpy()[:, :k], want[2].numpy()) and not sub[2].numpy()[:, k:].any()
+        k = want[3].shape[1]
+        assert np.array_equal(sub[3].numpy()[:, :k], want[3].numpy()) and not sub[3].numpy()[:, k:].any()
+        assert sub[4] == want[4]
+    synthetic.set_batch_nodeID(trees)
