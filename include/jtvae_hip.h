@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 5
+#define JTVAE_ABI_VERSION 6
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -136,12 +136,6 @@ int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, con
                          const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N,
                          int32_t K, int32_t accumulate, void* stream);
 
-/* out[c] (+)= sum_m X[m,c] for c < N (bias gradients), fixed summation order.
- * workspace: jtvae_colsum_workspace_bytes(M,N). */
-size_t jtvae_colsum_workspace_bytes(int32_t M, int32_t N);
-int jtvae_colsum(const float* X, int32_t ldx, float* out, int32_t M, int32_t N, int32_t accumulate,
-                 void* workspace, size_t workspace_bytes, void* stream);
-
 /* Up to JTVAE_PACK_MAX copies / transposes in one launch: the weights of a module laid out as
  * 16-byte-row GEMM operands.  transpose == 0: dst[r, c] = src[r, c]; transpose != 0:
  * dst[c, r] = src[r, c]; r < rows, c < cols; the remaining columns of every destination row up
@@ -157,10 +151,6 @@ typedef struct jtvae_pack_item {
   int32_t transpose;
 } jtvae_pack_item_t;
 int jtvae_pack_batch(const jtvae_pack_item_t* items, int32_t n_items, void* stream);
-
-/* dst[c,r] = src[r,c] for r < rows, c < cols (weight transposes for the dgrad GEMMs). */
-int jtvae_transpose(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows,
-                    int32_t cols, void* stream);
 
 /* dst[r, 0:cols] = src[r, 0:cols]; dst columns [cols, ld_dst) = 0.  Any alignment.  Moves rows
  * between torch's dense [rows, H] tensors and the padded row buffers. */
@@ -184,10 +174,6 @@ int jtvae_csr_gather_sum(float* out, const float* src0, int32_t n_src0, const fl
                          const int32_t* rowptr, const int32_t* col, int32_t n_rows, int32_t H,
                          int32_t ld, const float* relu_mask, int32_t accumulate, float* acc2,
                          void* stream);
-
-/* out[m] = sum_{t < n_slabs} X[t*slab_stride + m*ld ...]  (sum of per-iteration gradients). */
-int jtvae_slab_sum(float* out, const float* X, int32_t n_slabs, size_t slab_stride, int32_t n_rows,
-                   int32_t H, int32_t ld, void* stream);
 
 /* Per-segment mean readout: out[b] = (1/len_b) * sum rows[start_b : start_b+len_b]
  * (fast_jtnn/mpn.py:103-107, fast_jtnn/jtmpn.py:105-110).  seg = int32 [n_seg,2] (start,len). */

@@ -705,34 +705,6 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   *o = accumulate ? *o + acc : acc;
 }
 
-// column sums: stage 1 sums a block of rows per column, stage 2 adds the block partials in order
-constexpr int CS_ROWS = 512;
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int ldx, int M, int N,
-                                                             float* __restrict__ part) {
-  int c = blockIdx.x * 256 + threadIdx.x;
-  int r0 = blockIdx.y * CS_ROWS;
-  int r1 = min(M, r0 + CS_ROWS);
-  if (c >= N) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int r = r0;
-  for (; r + 4 <= r1; r += 4) {
-    a0 += X[(size_t)(r + 0) * ldx + c];
-    a1 += X[(size_t)(r + 1) * ldx + c];
-    a2 += X[(size_t)(r + 2) * ldx + c];
-    a3 += X[(size_t)(r + 3) * ldx + c];
-  }
-  for (; r < r1; ++r) a0 += X[(size_t)r * ldx + c];
-  part[(size_t)blockIdx.y * N + c] = (a0 + a1) + (a2 + a3);
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblk, int N,
-                                                           float* __restrict__ out, int accumulate) {
-  int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
-  float acc = 0.f;
-  for (int b = 0; b < nblk; ++b) acc += part[(size_t)b * N + c];
-  out[c] = accumulate ? out[c] + acc : acc;
-}
-
 inline bool aligned16(const void* p, int ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ld & 3) == 0); }
 inline int launch_status() {
   hipError_t e = hipGetLastError();
@@ -983,28 +955,6 @@ int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, con
   // contents the previous call left in the array never need clearing
   return gemm_tn_run(X, ldx, x_rows, Y, ldy, y_rows, dW, lddw, dbias, M, N, K, accumulate, ws, TN_SCRATCH_BYTES,
                      (hipStream_t)stream);
-}
-
-size_t jtvae_colsum_workspace_bytes(int32_t M, int32_t N) {
-  if (M < 0 || N <= 0) return 0;
-  size_t nblk = (size_t)(M + CS_ROWS - 1) / CS_ROWS;
-  if (nblk < 1) nblk = 1;
-  return nblk * N * sizeof(float);
-}
-
-int jtvae_colsum(const float* X, int32_t ldx, float* out, int32_t M, int32_t N, int32_t accumulate,
-                 void* workspace, size_t workspace_bytes, void* stream) {
-  if (M < 0 || N <= 0 || ldx < N) return JTVAE_E_SHAPE;
-  if (!X || !out || !workspace) return JTVAE_E_NULL;
-  if (workspace_bytes < jtvae_colsum_workspace_bytes(M, N)) return JTVAE_E_WORKSPACE;
-  int nblk = (M + CS_ROWS - 1) / CS_ROWS;
-  hipStream_t s = (hipStream_t)stream;
-  if (nblk > 0)
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nblk), dim3(256), 0, s, X, ldx, M, N,
-                       (float*)workspace);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)workspace, nblk, N,
-                     out, accumulate);
-  return launch_status();
 }
 
 int jtvae_abi_version(void) { return JTVAE_ABI_VERSION; }

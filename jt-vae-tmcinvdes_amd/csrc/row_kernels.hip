@@ -1,5 +1,5 @@
 // HBM-bound row kernels of the encoder path: CSR neighbour gather-sum (forward and,
-// on the transposed graph, backward), per-molecule mean readout, slab sums, copies.
+// on the transposed graph, backward), per-molecule mean readout, copies.
 //
 // One thread = one float4 of one output row; a row's neighbour rows are read with
 // 16-byte loads by consecutive lanes (coalesced 1.8 KB row reads), summed in
@@ -56,28 +56,6 @@ __global__ __launch_bounds__(JTVAE_BLOCK) void csr_gather_sum_kernel(
   }
 }
 
-__global__ __launch_bounds__(JTVAE_BLOCK) void slab_sum_kernel(float* __restrict__ out,
-                                                               const float* __restrict__ X, int n_slabs,
-                                                               size_t slab_stride, long total, int h4, int H,
-                                                               int ld) {
-  RowPos p = row_pos(total, h4);
-  if (!p.ok) return;
-  float4 acc = f4zero();
-  int t = 0;
-  for (; t + 4 <= n_slabs; t += 4) {
-    float4 a = *rowp(X + (size_t)(t + 0) * slab_stride, p.row, ld, p.c4);
-    float4 b = *rowp(X + (size_t)(t + 1) * slab_stride, p.row, ld, p.c4);
-    float4 c = *rowp(X + (size_t)(t + 2) * slab_stride, p.row, ld, p.c4);
-    float4 d = *rowp(X + (size_t)(t + 3) * slab_stride, p.row, ld, p.c4);
-    acc = acc + a;
-    acc = acc + b;
-    acc = acc + c;
-    acc = acc + d;
-  }
-  for (; t < n_slabs; ++t) acc = acc + *rowp(X + (size_t)t * slab_stride, p.row, ld, p.c4);
-  *rowp(out, p.row, ld, p.c4) = zero_pad(acc, p.c4, H);
-}
-
 __global__ __launch_bounds__(JTVAE_BLOCK) void segment_mean_kernel(float* __restrict__ out,
                                                                    const float* __restrict__ rows,
                                                                    const int* __restrict__ seg, long total,
@@ -132,24 +110,6 @@ __global__ __launch_bounds__(JTVAE_BLOCK) void copy_rows_kernel(const float* __r
   long r = gid / ld_dst;
   int c = (int)(gid - r * ld_dst);
   dst[gid] = c < cols ? src[r * ld_src + c] : 0.f;
-}
-
-// 32x32 tiles through LDS: coalesced on both sides
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int ld_src,
-                                                        float* __restrict__ dst, int ld_dst, int rows,
-                                                        int cols) {
-  __shared__ float tile[32][33];
-  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  for (int i = ty; i < 32; i += 8) {
-    int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < rows && c < cols) ? src[(size_t)r * ld_src + c] : 0.f;
-  }
-  __syncthreads();
-  for (int i = ty; i < 32; i += 8) {
-    int c = c0 + i, r = r0 + tx;  // dst[c][r]
-    if (c < cols && r < rows) dst[(size_t)c * ld_dst + r] = tile[tx][i];
-  }
 }
 
 // Several small matrices (the Linear weights of one module) packed or transposed into 16-byte-row
@@ -318,19 +278,6 @@ int jtvae_csr_gather_sum(float* out, const float* src0, int32_t n_src0, const fl
   return launch_status();
 }
 
-int jtvae_slab_sum(float* out, const float* X, int32_t n_slabs, size_t slab_stride, int32_t n_rows, int32_t H,
-                   int32_t ld, void* stream) {
-  if (n_rows < 0 || n_slabs < 0 || H <= 0 || H > ld || (slab_stride & 3)) return JTVAE_E_SHAPE;
-  if (n_rows == 0) return 0;
-  JT_CHECK(check_rows(out, ld));
-  JT_CHECK(check_rows(X, ld));
-  int h4 = ld / 4;
-  long total = (long)n_rows * h4;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, out, X,
-                     n_slabs, slab_stride, total, h4, H, ld);
-  return launch_status();
-}
-
 int jtvae_segment_mean(float* out, const float* rows, const int32_t* seg, int32_t n_seg, int32_t H, int32_t ld,
                        void* stream) {
   if (n_seg < 0 || H <= 0 || H > ld) return JTVAE_E_SHAPE;
@@ -368,16 +315,6 @@ int jtvae_copy_rows(const float* src, int32_t ld_src, float* dst, int32_t ld_dst
   long total = (long)rows * ld_dst;
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, src,
                      ld_src, dst, ld_dst, total, cols);
-  return launch_status();
-}
-
-int jtvae_transpose(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols,
-                    void* stream) {
-  if (rows <= 0 || cols <= 0 || cols > ld_src || rows > ld_dst) return JTVAE_E_SHAPE;
-  if (!src || !dst) return JTVAE_E_NULL;
-  dim3 grid((cols + 31) / 32, (rows + 31) / 32);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, rows,
-                     cols);
   return launch_status();
 }
 

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Epilogue(C.Structure):
@@ -93,10 +93,7 @@ SIGNATURES = {
                                 _vp]),
     "jtvae_gemm_tn_static_max_bytes": (_sz, []),
     "jtvae_gemm_tn_static": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp]),
-    "jtvae_colsum_workspace_bytes": (_sz, [_i32, _i32]),
-    "jtvae_colsum": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "jtvae_pack_batch": (C.c_int, [C.POINTER(PackItem), _i32, _vp]),
-    "jtvae_transpose": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_segment_ce": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "jtvae_prep_padded_to_csr": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
     "jtvae_prep_transpose_csr": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
@@ -106,7 +103,6 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _vp, _vp]),
     "jtvae_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_csr_gather_sum": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
-    "jtvae_slab_sum": (C.c_int, [_vp, _vp, _i32, _sz, _i32, _i32, _i32, _vp]),
     "jtvae_segment_mean": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_segment_mean_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_gru_iter0": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -309,13 +305,6 @@ def gemm_tn(X, ldx, Y, ldy, dW, lddw, M, N, K, accumulate, device, x_rows=None, 
          nbytes=4 * (M * N + M * K + N * K), flops=2 * M * N * K, tag="M=%d N=%d K=%d" % (M, N, K))
 
 
-def colsum(X, ldx, out, M, N, accumulate, device):
-    nbytes = lib.jtvae_colsum_workspace_bytes(M, N)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
-    _run("colsum", lib.jtvae_colsum, (X, ldx, out, M, N, int(accumulate), ws.data_ptr(), nbytes, stream_ptr()),
-         nbytes=4 * (M * N + N))
-
-
 def pack_batch(items):
     """items: list of (src_ptr, ld_src, dst_ptr, ld_dst, rows, cols, transpose); one launch per 16."""
     for i in range(0, len(items), PACK_MAX):
@@ -324,11 +313,6 @@ def pack_batch(items):
                                                 cols=it[5], transpose=it[6]) for it in chunk])
         _run("pack_batch", lib.jtvae_pack_batch, (arr, len(chunk), stream_ptr()),
              nbytes=sum(8 * it[4] * it[5] for it in chunk))
-
-
-def transpose(src, ld_src, dst, ld_dst, nrows, ncols):
-    _run("transpose", lib.jtvae_transpose, (src, ld_src, dst, ld_dst, nrows, ncols, stream_ptr()),
-         nbytes=8 * nrows * ncols)
 
 
 def copy_rows(src, ld_src, dst, ld_dst, nrows, ncols):
@@ -344,11 +328,6 @@ def csr_gather_sum(out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mas
     _run("csr_gather_sum", lib.jtvae_csr_gather_sum,
          (out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask, int(accumulate), acc2, stream_ptr()),
          nbytes=nbytes)
-
-
-def slab_sum(out, X, n_slabs, slab_stride, n_rows, H, ld):
-    _run("slab_sum", lib.jtvae_slab_sum, (out, X, n_slabs, slab_stride, n_rows, H, ld, stream_ptr()),
-         nbytes=4 * H * n_rows * (n_slabs + 1))
 
 
 def segment_mean(out, rows_, seg, n_seg, H, ld, n_rows=None):

@@ -21,6 +21,8 @@ gathers read from ``[tree messages ; bond messages]``.
 """
 from __future__ import annotations
 
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
 
@@ -33,6 +35,10 @@ BOND_FDIM = MPN_BOND_FDIM  # 12, fast_jtnn/mpn.py:36
 MAX_NB = MPN_MAX_NB  # 6,  fast_jtnn/mpn.py:37
 
 
+_PACK_CACHE = OrderedDict()  # layout key -> (weights, their versions, packed buffers)
+_PACK_CACHE_MAX = 16
+
+
 def pack_weights(specs):
     """GEMM operands of Linear weights, all produced by one launch.
 
@@ -40,7 +46,21 @@ def pack_weights(specs):
     weight as ``[out, round4(ncols)]``; transposed: the same block turned, ``[ncols, round4(out)]`` (the
     operand of the dgrad GEMM).  Padding columns are zero.  Returns the buffers in order; they share one
     allocation.
+
+    The result is kept until one of the weights changes (an optimizer step bumps a tensor's version
+    counter), so inference and the two passes of a training step pack each layout once per weight update.
+    The entry holds the weight tensors themselves, which rules out a recycled object id or address.
     """
+    key = tuple((id(w), col0, ncols, bool(transposed)) for w, col0, ncols, transposed in specs)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        ws, versions, bufs, store = hit
+        if all(w is c for (w, _, _, _), c in zip(specs, ws)) and \
+                all(w._version == v for (w, _, _, _), v in zip(specs, versions)):
+            _PACK_CACHE.move_to_end(key)
+            if store.is_cuda:  # a later step may run on another stream than the one that packed
+                store.record_stream(torch.cuda.current_stream(store.device))
+            return bufs
     shapes, total = [], 0
     for w, col0, ncols, transposed in specs:
         out_f = w.shape[0]
@@ -59,6 +79,9 @@ def pack_weights(specs):
         bufs.append(buf)
         items.append((K.ptr(w, col0), w.shape[1], buf.data_ptr(), ld, w.shape[0], ncols, 1 if transposed else 0))
     K.pack_batch(items)
+    _PACK_CACHE[key] = ([w for w, _, _, _ in specs], [w._version for w, _, _, _ in specs], bufs, store)
+    while len(_PACK_CACHE) > _PACK_CACHE_MAX:
+        _PACK_CACHE.popitem(last=False)
     return bufs
 
 

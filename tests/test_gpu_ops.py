@@ -133,7 +133,7 @@ def test_gemm_nt_gru_blend_and_mul_acc(K, M, pad):
 
 @pytest.mark.parametrize("M,N,Kd", [(1000, 450, 450), (70000, 450, 450), (5000, 450, 39), (31, 96, 51),
                                     (4097, 450, 44), (700, 130, 96), (300, 450, 480)])
-def test_gemm_tn_and_colsum(K, M, N, Kd):
+def test_gemm_tn_and_bias_column(K, M, N, Kd):
     rs = np.random.RandomState(M)
     X = rs.standard_normal((M, N)).astype(np.float32)
     Y = rs.standard_normal((M, Kd)).astype(np.float32)
@@ -158,10 +158,6 @@ def test_gemm_tn_and_colsum(K, M, N, Kd):
     K.gemm_tn(Xd.data_ptr(), ldx, Yd.data_ptr(), ldy, dW3.data_ptr(), Kd + 5, M, N, Kd, False, "cuda")
     torch.cuda.synchronize()
     assert torch.equal(dW2, dW3)
-    out = torch.zeros(N, device="cuda")
-    K.colsum(Xd.data_ptr(), ldx, out.data_ptr(), M, N, False, "cuda")
-    torch.cuda.synchronize()
-    assert np.abs(out.cpu().numpy() - X.astype(np.float64).sum(0)).max() / scale < 2e-5
     # the same column sums ride along with the contraction (bias gradient), without disturbing dW
     db = torch.full((N,), 3.0, device="cuda")
     dW4 = torch.from_numpy(base.copy()).cuda()
@@ -176,16 +172,13 @@ def test_gemm_tn_and_colsum(K, M, N, Kd):
     assert np.abs(db.cpu().numpy() - 2 * X.astype(np.float64).sum(0)).max() / scale < 4e-5
 
 
-def test_transpose_and_copy_rows(K):
+def test_copy_rows(K):
     rs = np.random.RandomState(1)
     W = rs.standard_normal((450, 489)).astype(np.float32)
     Wd = torch.from_numpy(W).cuda()
-    T = torch.zeros((450, 452), device="cuda")
-    K.transpose(K.ptr(Wd, 39), 489, T.data_ptr(), 452, 450, 450)  # columns 39.. of W_o, transposed
     P = torch.empty((450, 40), device="cuda")
     K.copy_rows(Wd.data_ptr(), 489, P.data_ptr(), 40, 450, 39)
     torch.cuda.synchronize()
-    assert np.array_equal(T[:, :450].cpu().numpy(), W[:, 39:].T)
     assert np.array_equal(P[:, :39].cpu().numpy(), W[:, :39]) and float(P[:, 39].abs().max()) == 0.0
 
 
@@ -258,7 +251,7 @@ def test_csr_gather_sum_variants(K, H):
     assert rel_err(acc2d[:, :H].cpu().numpy(), acc2 + want) < 1e-6
 
 
-def test_segment_mean_and_backward_and_slab_sum(K):
+def test_segment_mean_and_backward(K):
     rs = np.random.RandomState(3)
     H, ld = 450, 452
     lens = rs.randint(1, 60, size=50)
@@ -282,13 +275,6 @@ def test_segment_mean_and_backward_and_slab_sum(K):
     want = dout[np.maximum(seg_of, 0)] / lens[np.maximum(seg_of, 0)][:, None] * (rows > 0)
     want[5] = 0
     assert rel_err(drows[:, :H].cpu().numpy(), want) < 1e-6
-    X = rs.standard_normal((7, 33, H)).astype(np.float32)
-    Xd = torch.zeros((7, 33, ld), device="cuda")
-    Xd[:, :, :H] = torch.from_numpy(X).cuda()
-    o = torch.empty((33, ld), device="cuda")
-    K.slab_sum(o.data_ptr(), Xd.data_ptr(), 7, 33 * ld, 33, H, ld)
-    torch.cuda.synchronize()
-    assert rel_err(o[:, :H].cpu().numpy(), X.astype(np.float64).sum(0)) < 1e-6
 
 
 def test_gru_kernels(K):
