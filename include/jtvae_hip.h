@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 6
+#define JTVAE_ABI_VERSION 7
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -213,6 +213,16 @@ int jtvae_gru_gate_gather(const float* h, const float* Uh, size_t slab_stride, i
                           const int32_t* sf, const float* Pr, const int32_t* wid, const int32_t* rowptr,
                           const int32_t* col, const int32_t* rows, int32_t n_rows, float* s, float* g,
                           float* t, int32_t H, int32_t ld, void* stream);
+
+/* Update of the active rows of one iteration in one launch (jtnn_enc.py:114-115,123-126; the decoder's
+ * nnutils.py:59-60,68-70):  z = sigmoid(S . Wz^T + Pz[wid]),  p = tanh(G . Wh^T + Ph[wid]),
+ * h' = (1 - z) s + z p, row zero_row of h' forced to 0.  S, G: the two neighbour sums of
+ * jtvae_gru_gate_gather (rows by message id, leading dimension ld); Wz = W_z[:, H:], Wh = W_h[:, H:]
+ * ([H, ldw]); Pz, Ph: the per-word tables; rows: message ids to update (NULL = 0 .. n_rows-1).  Z, P, Hout
+ * by message id.  Results are those of two jtvae_gemm_nt calls (sigmoid epilogue, then GRU_BLEND). */
+int jtvae_gru_update(const float* S, const float* G, int32_t ld, const float* Wz, const float* Wh, int32_t ldw,
+                     const float* Pz, const float* Ph, int32_t ldp, const int32_t* wid, const int32_t* rows,
+                     int32_t n_rows, float* Z, float* P, float* Hout, int32_t H, int32_t zero_row, void* stream);
 
 /* Backward of the blend h' = ((1-z) s + z p) * mask (jtnn_enc.py:115,124-126) for the rows that
  * receive gradient at iteration t_iter:

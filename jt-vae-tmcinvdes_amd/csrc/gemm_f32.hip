@@ -555,13 +555,224 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_small_pair_kernel(NtArgs a, Nt
 }
 
 // ---------------------------------------------------------------------------------------
+// GRU update of one level in ONE launch (fast_jtnn/jtnn_enc.py:115,124-126; fast_jtnn/nnutils.py:59-70):
+//   z = sigmoid(S . Wz^T + Pz[wid]),  p = tanh(G . Wh^T + Ph[wid]),  h' = (1 - z) s + z p
+// Two products with different operands feed one epilogue, so a block keeps two accumulators for its
+// output tile and runs the K loop twice (same LDS tiles, same summation order as gemm_nt); z never
+// makes a round trip through memory before the blend.  Tiled form: 128 x 32 tiles (levels of a few
+// hundred to ~10 000 rows); small form: one 32 x 32 tile per block with the whole K extent in LDS.
+struct GruUpArgs {
+  const float* S;
+  const float* G;
+  const float* Wz;
+  const float* Wh;
+  const float* Pz;
+  const float* Ph;
+  const int* wid;
+  const int* rows;  // nullable: message id of launch row i
+  float* Z;
+  float* P;
+  float* Hout;
+  int ld, ldw, ldp;
+  int M, N, K, zero_row;
+  int n_tiles_n, n_blocks;
+};
+
+// K loop of the 128 x 32 tile, operands float4-addressable: acc += A[rows, :] . W[n0.., :]^T
+__device__ __forceinline__ void nt_kloop_narrow(const float* A, int lda, const float* W, int ldw, const int* a_rows,
+                                                int M, int N, int K, int m0, int n0, float* As, float* Bs,
+                                                f32x16& acc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int srow = tid >> 3, sc4 = tid & 7;
+  float4 ra[NT_BM / 32], rb;
+  const float* a_row[NT_BM / 32];
+#pragma unroll
+  for (int i = 0; i < NT_BM / 32; ++i) {
+    int m = min(m0 + srow + 32 * i, M - 1);
+    if (a_rows) m = a_rows[m];
+    a_row[i] = A + (size_t)m * lda;
+  }
+  const float* b_row = W + (size_t)min(n0 + srow, N - 1) * ldw;
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NT_BM / 32; ++i) ra[i] = load4_raw<true>(a_row[i], k0 + 4 * sc4, K);
+    rb = load4_raw<true>(b_row, k0 + 4 * sc4, K);
+  };
+  auto store_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NT_BM / 32; ++i)
+      *reinterpret_cast<float4*>(&As[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
+          mask4(ra[i], m0 + srow + 32 * i < M, k0 + 4 * sc4, K);
+    *reinterpret_cast<float4*>(&Bs[srow * NT_LDS + 4 * sc4]) = mask4(rb, n0 + srow < N, k0 + 4 * sc4, K);
+  };
+  const int nk = (K + NT_BK - 1) / NT_BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const float* a_frag = &As[(wave * 32 + (lane & 31)) * NT_LDS + 4 * (lane >> 5)];
+  const float* b_frag = &Bs[(lane & 31) * NT_LDS + 4 * (lane >> 5)];
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles((kt + 1) * NT_BK);
+    const int kk_end = min(NT_BK / 8, (K - kt * NT_BK + 7) >> 3);
+#pragma unroll
+    for (int kk = 0; kk < NT_BK / 8; ++kk) {
+      if (kk >= kk_end) break;
+      const float4 av = *reinterpret_cast<const float4*>(a_frag + 8 * kk);
+      const float4 bv = *reinterpret_cast<const float4*>(b_frag + 8 * kk);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      store_tiles((kt + 1) * NT_BK);
+      __syncthreads();
+    }
+  }
+}
+
+// z, p, h' of one output row at columns [n, n + 4) from the two pre-activation sums
+__device__ __forceinline__ void gru_up_store(const GruUpArgs& a, int m, int n, float4 vz, float4 vp) {
+  if (n >= a.ld) return;
+  const int nv = a.N - n;
+  const int w = a.wid[m];
+  const float4 pz = ld4(a.Pz + (size_t)w * a.ldp + n);
+  const float4 ph = ld4(a.Ph + (size_t)w * a.ldp + n);
+  const float4 sv = ld4(a.S + (size_t)m * a.ld + n);
+  float4 z, pp, h;
+  z.x = sigmoidf_fast(vz.x + pz.x);
+  z.y = sigmoidf_fast(vz.y + pz.y);
+  z.z = sigmoidf_fast(vz.z + pz.z);
+  z.w = sigmoidf_fast(vz.w + pz.w);
+  pp.x = tanhf(vp.x + ph.x);
+  pp.y = tanhf(vp.y + ph.y);
+  pp.z = tanhf(vp.z + ph.z);
+  pp.w = tanhf(vp.w + ph.w);
+  h.x = fmaf(z.x, pp.x - sv.x, sv.x);  // (1 - z) s + z p
+  h.y = fmaf(z.y, pp.y - sv.y, sv.y);
+  h.z = fmaf(z.z, pp.z - sv.z, sv.z);
+  h.w = fmaf(z.w, pp.w - sv.w, sv.w);
+  if (m == a.zero_row) h = make_float4(0.f, 0.f, 0.f, 0.f);
+  st4(a.Z + (size_t)m * a.ld + n, keep_cols(z, nv));
+  st4(a.P + (size_t)m * a.ld + n, keep_cols(pp, nv));
+  st4(a.Hout + (size_t)m * a.ld + n, keep_cols(h, nv));
+}
+
+__global__ __launch_bounds__(256, 4) void gru_update_kernel(GruUpArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[(NT_BM + 32) * NT_LDS];
+  float* As = smem;
+  float* Bs = smem + NT_BM * NT_LDS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = xcd_remap(blockIdx.x, a.n_blocks);
+  const int m0 = (tile / a.n_tiles_n) * NT_BM;
+  const int n0 = (tile % a.n_tiles_n) * 32;
+  f32x16 acc_z, acc_p;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_z[r] = acc_p[r] = 0.f;
+  nt_kloop_narrow(a.S, a.ld, a.Wz, a.ldw, a.rows, a.M, a.N, a.K, m0, n0, As, Bs, acc_z);
+  nt_kloop_narrow(a.G, a.ld, a.Wh, a.ldw, a.rows, a.M, a.N, a.K, m0, n0, As, Bs, acc_p);
+  // both accumulators through the wave's own LDS patch (the operand tiles are dead after the last barrier
+  // of the loop), so that a lane holds float4s along rows
+  float* stage = smem + wave * (32 * NT_EPI_LD);
+  float4 vz[4], vp[4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * NT_EPI_LD + (lane & 31)] = acc_z[r];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vz[j] = ld4(&stage[((lane >> 3) + 8 * j) * NT_EPI_LD + 4 * (lane & 7)]);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * NT_EPI_LD + (lane & 31)] = acc_p[r];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) vp[j] = ld4(&stage[((lane >> 3) + 8 * j) * NT_EPI_LD + 4 * (lane & 7)]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = m0 + wave * 32 + (lane >> 3) + 8 * j;
+    if (i >= a.M) continue;
+    const int m = a.rows ? a.rows[i] : i;
+    gru_up_store(a, m, n0 + 4 * (lane & 7), vz[j], vp[j]);
+  }
+}
+
+// one product of the small form: the 32 x 32 tile of A[rows] . W^T, K split over the four waves, partial
+// tiles added through LDS in fixed order; returns this thread's four consecutive columns of row (tid >> 3)
+__device__ __forceinline__ float4 nt_small_product(const float* A, int lda, const float* W, int ldw, const int* a_rows,
+                                                   int M, int N, int K, int m0, int n0, float* sm) {
+  float* As = sm;
+  float* Ws = sm + 32 * SM_LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c4n = (K + 3) >> 2;
+  float4 va[SM_PER_THREAD], vw[SM_PER_THREAD];
+#pragma unroll
+  for (int u = 0; u < SM_PER_THREAD; ++u) {
+    const int idx = tid + 256 * u;
+    const int row = min(idx / SM_C4, 31), c4 = idx % SM_C4;
+    int m = min(m0 + row, M - 1);
+    if (a_rows) m = a_rows[m];
+    const int n = min(n0 + row, N - 1);
+    const int k = c4 < c4n ? 4 * c4 : 0;
+    va[u] = *reinterpret_cast<const float4*>(A + (size_t)m * lda + k);
+    vw[u] = *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k);
+  }
+#pragma unroll
+  for (int u = 0; u < SM_PER_THREAD; ++u) {
+    const int idx = tid + 256 * u;
+    if (idx < 32 * SM_C4) {
+      const int row = idx / SM_C4, c4 = idx % SM_C4;
+      const bool in_k = c4 < c4n;
+      *reinterpret_cast<float4*>(&As[row * SM_LD + 4 * c4]) = mask4(va[u], in_k && m0 + row < M, 4 * c4, K);
+      *reinterpret_cast<float4*>(&Ws[row * SM_LD + 4 * c4]) = mask4(vw[u], in_k && n0 + row < N, 4 * c4, K);
+    }
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* a_frag = &As[(lane & 31) * SM_LD + 4 * (lane >> 5)];
+  const float* w_frag = &Ws[(lane & 31) * SM_LD + 4 * (lane >> 5)];
+  const int groups = (K + 7) >> 3;
+  for (int g = wave; g < groups; g += 4) {
+    const float4 av = *reinterpret_cast<const float4*>(a_frag + 8 * g);
+    const float4 bv = *reinterpret_cast<const float4*>(w_frag + 8 * g);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+  }
+  __syncthreads();
+  float* red = sm + wave * (32 * 33);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[r];
+  __syncthreads();
+  const int o = (tid >> 3) * 33 + (tid & 7) * 4;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = ((sm[o + j] + sm[o + j + 32 * 33]) + sm[o + j + 2 * 32 * 33]) + sm[o + j + 3 * 32 * 33];
+  __syncthreads();  // the LDS is free for the next product
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ __launch_bounds__(256, 1) void gru_update_small_kernel(GruUpArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[2 * 32 * SM_LD];
+  const int m0 = (blockIdx.x / a.n_tiles_n) * 32;
+  const int n0 = (blockIdx.x % a.n_tiles_n) * 32;
+  const float4 vz = nt_small_product(a.S, a.ld, a.Wz, a.ldw, a.rows, a.M, a.N, a.K, m0, n0, sm);
+  const float4 vp = nt_small_product(a.G, a.ld, a.Wh, a.ldw, a.rows, a.M, a.N, a.K, m0, n0, sm);
+  const int i = m0 + (threadIdx.x >> 3);
+  if (i < a.M) gru_up_store(a, a.rows ? a.rows[i] : i, n0 + 4 * (threadIdx.x & 7), vz, vp);
+}
+
+// ---------------------------------------------------------------------------------------
 // gemm_tn: partial[s][n][k] = sum_{m in slab s} X[xr(m)][n] * Y[yr(m)][k]
-// Block tile 128 (n) x 96 (k); wave w owns n rows [32w, 32w+32) and three 32x32 accumulators.
+// Block tile 128 (n) x 96 (k) (64 / 32 for narrow feature operands); wave w owns n rows [32w, 32w+32) and one
+// 32x32 accumulator per 32 k columns.
 // Operand tiles sit in LDS row-major as loaded (m-major): for one MFMA step lane l needs
 // X[m = 2*step + (l>>5)][n = l&31], i.e. 32 consecutive floats per half-wave: conflict-free
 // ds_read_b32 with no transpose anywhere.
 constexpr int TN_BN = 128;
-constexpr int TN_BKK = 96;
 constexpr int TN_BM = 32;
 
 struct TnArgs {
@@ -588,27 +799,31 @@ __device__ __forceinline__ float4 mask4_ones(float4 v, bool row_ok, int k, int K
   return v;
 }
 
-template <bool VEC>
+// NACC = 32-column accumulators per wave: 3 (k tile 96) for the square products, 2 / 1 when the reduced-over
+// operand is a narrow feature matrix (K + bias column <= 64 / 32): no MFMA is spent on padding columns.
+template <bool VEC, int NACC>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
+  constexpr int BKK = 32 * NACC;  // k tile
+  constexpr int Y4 = 8 * NACC;    // float4 per staged Y row
   __shared__ __attribute__((aligned(16))) float Xs[TN_BM * TN_BN];
-  __shared__ __attribute__((aligned(16))) float Ys[TN_BM * TN_BKK];
+  __shared__ __attribute__((aligned(16))) float Ys[TN_BM * BKK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles = a.tiles_n * a.tiles_k;
   const int split = blockIdx.x / tiles;
   const int tile = blockIdx.x % tiles;
   const int n0 = (tile / a.tiles_k) * TN_BN;
-  const int k0 = (tile % a.tiles_k) * TN_BKK;
+  const int k0 = (tile % a.tiles_k) * BKK;
   const int m_beg = split * a.rows_per_split;
   const int m_end = min(a.M, m_beg + a.rows_per_split);
 
-  f32x16 acc[3];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-  float4 rx[4], ry[3];
-  int ix[4], iy[3];  // source rows of the NEXT tile to load (row lists resolved one tile ahead)
+  float4 rx[4], ry[NACC];
+  int ix[4], iy[NACC];  // source rows of the NEXT tile to load (row lists resolved one tile ahead)
   auto load_rows = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -616,8 +831,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
       ix[i] = a.x_rows ? a.x_rows[m] : m;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      int m = min(mb + (tid + 256 * i) / 24, m_end - 1);
+    for (int i = 0; i < NACC; ++i) {
+      int m = min(mb + (tid + 256 * i) / Y4, m_end - 1);
       iy[i] = a.y_rows ? a.y_rows[m] : m;
     }
   };
@@ -626,8 +841,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
     for (int i = 0; i < 4; ++i)
       rx[i] = load4_raw<VEC>(a.X + (size_t)ix[i] * a.ldx, n0 + 4 * ((tid + 256 * i) & 31), a.N);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      ry[i] = load4_raw<VEC>(a.Y + (size_t)iy[i] * a.ldy, k0 + 4 * ((tid + 256 * i) % 24), a.K);
+    for (int i = 0; i < NACC; ++i)
+      ry[i] = load4_raw<VEC>(a.Y + (size_t)iy[i] * a.ldy, k0 + 4 * ((tid + 256 * i) % Y4), a.K);
   };
   auto store_tiles = [&](int mb) {
 #pragma unroll
@@ -637,10 +852,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
           mask4(rx[i], mb + (idx >> 5) < m_end, n0 + 4 * (idx & 31), a.N);
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NACC; ++i) {
       int idx = tid + 256 * i;
-      *reinterpret_cast<float4*>(&Ys[(idx / 24) * TN_BKK + 4 * (idx % 24)]) =
-          mask4_ones(ry[i], mb + idx / 24 < m_end, k0 + 4 * (idx % 24), a.K, a.ones_col);
+      *reinterpret_cast<float4*>(&Ys[(idx / Y4) * BKK + 4 * (idx % Y4)]) =
+          mask4_ones(ry[i], mb + idx / Y4 < m_end, k0 + 4 * (idx % Y4), a.K, a.ones_col);
     }
   };
 
@@ -651,7 +866,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
     if (m_beg + TN_BM < m_end) load_rows(m_beg + TN_BM);
     __syncthreads();
     const float* xf = &Xs[(lane >> 5) * TN_BN + wave * 32 + (lane & 31)];
-    const float* yf = &Ys[(lane >> 5) * TN_BKK + (lane & 31)];
+    const float* yf = &Ys[(lane >> 5) * BKK + (lane & 31)];
     for (int mb = m_beg; mb < m_end; mb += TN_BM) {
       const bool more = mb + TN_BM < m_end;
       if (more) {
@@ -661,12 +876,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
       for (int st = 0; st < TN_BM / 2; ++st) {
         float xv = xf[2 * st * TN_BN];
-        float y0 = yf[2 * st * TN_BKK];
-        float y1 = yf[2 * st * TN_BKK + 32];
-        float y2 = yf[2 * st * TN_BKK + 64];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, y0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, y1, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, y2, acc[2], 0, 0, 0);
+        float yv[NACC];
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) yv[t] = yf[2 * st * BKK + 32 * t];
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, yv[t], acc[t], 0, 0, 0);
       }
       __syncthreads();
       if (more) {
@@ -678,7 +892,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
 
   float* P = a.P + (size_t)split * a.N * a.ldp;
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
+  for (int t = 0; t < NACC; ++t) {
     const int k = k0 + 32 * t + (lane & 31);
     if (k >= a.K + a.ones_col) continue;
 #pragma unroll
@@ -712,12 +926,13 @@ inline int launch_status() {
 }
 
 struct TnPlan {
-  int tiles_n, tiles_k, splits, rows_per_split, ldp;
+  int tiles_n, tiles_k, splits, rows_per_split, ldp, nacc;
 };
 inline TnPlan tn_plan(int M, int N, int K, int ones_col) {
   TnPlan p;
+  p.nacc = K + ones_col <= 32 ? 1 : (K + ones_col <= 64 ? 2 : 3);
   p.tiles_n = (N + TN_BN - 1) / TN_BN;
-  p.tiles_k = (K + ones_col + TN_BKK - 1) / TN_BKK;
+  p.tiles_k = (K + ones_col + 32 * p.nacc - 1) / (32 * p.nacc);
   int tiles = p.tiles_n * p.tiles_k;
   int want = (M + 255) / 256;               // at least 256 rows per slab
   int cap = (1024 + tiles - 1) / tiles;     // about four blocks per CU in total
@@ -848,10 +1063,21 @@ int gemm_tn_run(const float* X, int32_t ldx, const int32_t* x_rows, const float*
   a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.rows_per_split = p.rows_per_split;
   a.ones_col = ones_col;
   int blocks = p.tiles_n * p.tiles_k * p.splits;
-  if (aligned16(X, ldx) && aligned16(Y, ldy))
-    hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(blocks), dim3(256), 0, s, a);
+  const bool vec = aligned16(X, ldx) && aligned16(Y, ldy);
+#define JTVAE_TN_LAUNCH(NACC)                                                                   \
+  do {                                                                                          \
+    if (vec)                                                                                    \
+      hipLaunchKernelGGL((gemm_tn_kernel<true, NACC>), dim3(blocks), dim3(256), 0, s, a);       \
+    else                                                                                        \
+      hipLaunchKernelGGL((gemm_tn_kernel<false, NACC>), dim3(blocks), dim3(256), 0, s, a);      \
+  } while (0)
+  if (p.nacc == 1)
+    JTVAE_TN_LAUNCH(1);
+  else if (p.nacc == 2)
+    JTVAE_TN_LAUNCH(2);
   else
-    hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(blocks), dim3(256), 0, s, a);
+    JTVAE_TN_LAUNCH(3);
+#undef JTVAE_TN_LAUNCH
   long total = (long)N * (K + ones_col);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.P, p.splits, N,
                      K, p.ldp, dW, lddw, dbias, accumulate);
@@ -921,6 +1147,43 @@ int jtvae_gemm_nt_pair(const jtvae_gemm_nt_problem_t* p0, const jtvae_gemm_nt_pr
   } else {
     if (p0->M > 0) launch_nt_any(a, vec_a, s);
     if (p1->M > 0) launch_nt_any(b, vec_b, s);
+  }
+  return launch_status();
+}
+
+int jtvae_gru_update(const float* S, const float* G, int32_t ld, const float* Wz, const float* Wh, int32_t ldw,
+                     const float* Pz, const float* Ph, int32_t ldp, const int32_t* wid, const int32_t* rows,
+                     int32_t n_rows, float* Z, float* P, float* Hout, int32_t H, int32_t zero_row, void* stream) {
+  if (n_rows < 0 || H <= 0 || ld < H || ldw < H || ldp < H) return JTVAE_E_SHAPE;
+  if (n_rows == 0) return 0;
+  if (!S || !G || !Wz || !Wh || !Pz || !Ph || !wid || !Z || !P || !Hout) return JTVAE_E_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = aligned16(S, ld) && aligned16(G, ld) && aligned16(Wz, ldw) && aligned16(Wh, ldw) &&
+                   aligned16(Pz, ldp) && aligned16(Ph, ldp) && aligned16(Z, ld) && aligned16(P, ld) &&
+                   aligned16(Hout, ld);
+  if (!vec || n_rows > narrow_max_rows() || (n_rows <= SM_MAX_ROWS && H > SM_KMAX)) {
+    // the general route: two products, the second with the blend epilogue
+    jtvae_epilogue_t e = jtvae_epilogue_t();
+    e.zero_row = -1;
+    e.add = Pz; e.ld_add = ldp; e.add_idx = wid; e.act = JTVAE_ACT_SIGMOID; e.a_rows = rows; e.c_rows = rows;
+    int rc = jtvae_gemm_nt(S, ld, Wz, ldw, Z, ld, n_rows, H, H, &e, stream);
+    if (rc) return rc;
+    e.add = Ph; e.act = JTVAE_ACT_NONE; e.mode = JTVAE_EPI_GRU_BLEND;
+    e.aux0 = Z; e.aux1 = S; e.out2 = Hout; e.ld_aux = ld; e.zero_row = zero_row;
+    return jtvae_gemm_nt(G, ld, Wh, ldw, P, ld, n_rows, H, H, &e, stream);
+  }
+  GruUpArgs a;
+  a.S = S; a.G = G; a.Wz = Wz; a.Wh = Wh; a.Pz = Pz; a.Ph = Ph; a.wid = wid; a.rows = rows;
+  a.Z = Z; a.P = P; a.Hout = Hout;
+  a.ld = ld; a.ldw = ldw; a.ldp = ldp;
+  a.M = n_rows; a.N = H; a.K = H; a.zero_row = zero_row;
+  a.n_tiles_n = (H + 31) / 32;
+  if (n_rows <= SM_MAX_ROWS) {
+    a.n_blocks = ((n_rows + 31) / 32) * a.n_tiles_n;
+    hipLaunchKernelGGL(gru_update_small_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
+  } else {
+    a.n_blocks = ((n_rows + NT_BM - 1) / NT_BM) * a.n_tiles_n;
+    hipLaunchKernelGGL(gru_update_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
   }
   return launch_status();
 }

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Epilogue(C.Structure):
@@ -108,6 +108,8 @@ SIGNATURES = {
     "jtvae_gru_iter0": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "jtvae_gru_gate_gather": (C.c_int, [_vp, _vp, _sz, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                         _i32, _i32, _vp]),
+    "jtvae_gru_update": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32,
+                                   _i32, _vp]),
     "jtvae_gru_bwd_pointwise": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
                                           _i32, _vp]),
     "jtvae_gru_bwd_gather": (C.c_int, [_vp, _vp, _sz, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
@@ -352,6 +354,14 @@ def gru_gate_gather(h, Uh, slab_stride, t_iter, sf, Pr, wid, rowptr, col, rows, 
     _run("gru_gate_gather", lib.jtvae_gru_gate_gather,
          (h, Uh, slab_stride, t_iter, sf, Pr, wid, rowptr, col, rows, n_rows, s, g, t, H, ld, stream_ptr()),
          nbytes=nbytes)
+
+
+def gru_update(S, G, ld, Wz, Wh, ldw, Pz, Ph, ldp, wid, rows, n_rows, Z, P, Hout, H, zero_row=0):
+    """Both products of a GRU level and the blend in one launch; priced as the two gemm_nt calls it replaces."""
+    _run("gemm_nt", lib.jtvae_gru_update, (S, G, ld, Wz, Wh, ldw, Pz, Ph, ldp, wid, rows, n_rows, Z, P, Hout, H,
+                                           zero_row, stream_ptr()),
+         nbytes=4 * (2 * n_rows * H + 2 * H * H + 4 * n_rows * H), flops=4 * n_rows * H * H,
+         tag="gru_update M=%d N=%d K=%d" % (n_rows, H, H))
 
 
 def gru_bwd_pointwise(dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre, dppre, ds, H, ld, pad_row=0):

@@ -89,14 +89,11 @@ class _TreeGRU:
             K.gru_gate_gather(hs.data_ptr(), us.data_ptr(), stride, t, sf_p, Pr.data_ptr(), wid_p,
                               mcsr.rowptr.data_ptr(), mcsr.col.data_ptr(), F.ptr(), F.n, ss[i].data_ptr(),
                               gs[i].data_ptr(), ts[i].data_ptr() if train else None, H, ld, nnz=F.nnz)
-            # z = sigmoid(W_z[:, H:] s + Pz[wid])
-            K.gemm_nt(ss[i].data_ptr(), ld, Wzh.data_ptr(), ld, zs[i].data_ptr(), ld, F.n, H, H,
-                      add=Pz.data_ptr(), ld_add=ld, add_idx=wid_p, act=K.ACT_SIGMOID, a_rows=F.ptr(), c_rows=F.ptr())
-            # p = tanh(W_h[:, H:] g + Ph[wid]);  h' = (1-z) s + z p, padding row kept zero
-            K.gemm_nt(gs[i].data_ptr(), ld, Whh.data_ptr(), ld, ps[i].data_ptr(), ld, F.n, H, H,
-                      add=Ph.data_ptr(), ld_add=ld, add_idx=wid_p, mode=K.EPI_GRU_BLEND,
-                      aux0=zs[i].data_ptr(), aux1=ss[i].data_ptr(), out2=h_out.data_ptr(), ld_aux=ld,
-                      a_rows=F.ptr(), c_rows=F.ptr(), zero_row=pad_row)
+            # z = sigmoid(W_z[:, H:] s + Pz[wid]);  p = tanh(W_h[:, H:] g + Ph[wid]);  h' = (1-z) s + z p with the
+            # padding row kept zero: both products and the blend in one launch
+            K.gru_update(ss[i].data_ptr(), gs[i].data_ptr(), ld, Wzh.data_ptr(), Whh.data_ptr(), ld, Pz.data_ptr(),
+                         Ph.data_ptr(), ld, wid_p, F.ptr(), F.n, zs[i].data_ptr(), ps[i].data_ptr(),
+                         h_out.data_ptr(), H, pad_row)
         if train and not compact:
             h = K.rows(NM, ld, dev)
             K.select_slab_rows(h.data_ptr(), hs.data_ptr(), stride, sched.sel_final.data_ptr(), NM, H, ld)

@@ -471,3 +471,53 @@ def test_gemm_nt_pair_equals_two_calls(K, M0, M1):
         assert torch.equal(x, y)
     if M0:
         assert float((out["pair"][0] - 1.0).abs().max()) > 0.0  # the first product did land
+
+
+@pytest.mark.parametrize("n_rows,with_rows", [(5, True), (300, False), (513, True), (4100, True), (12000, False)])
+def test_gru_update_equals_the_two_products_it_replaces(K, n_rows, with_rows):
+    """z, p and the blended state of one GRU level from one launch, bit for bit what two gemm_nt calls
+    (sigmoid epilogue, then the blend epilogue) produce, for the small, the tiled and the general route."""
+    rs = np.random.RandomState(n_rows)
+    H, ld, V = 450, 452, 37
+    NM = n_rows + 9
+    def buf(n, scale=1.0):
+        a = np.zeros((n, ld), np.float32)
+        a[:, :H] = rs.standard_normal((n, H)).astype(np.float32) * scale
+        return torch.from_numpy(a).cuda()
+    S, G = buf(NM, 0.5), buf(NM, 0.5)
+    Wz, Wh = buf(H, 0.05), buf(H, 0.05)
+    Pz, Ph = buf(V), buf(V)
+    wid = torch.from_numpy(rs.randint(0, V, size=NM).astype(np.int32)).cuda()
+    rows = None
+    if with_rows:
+        r = rs.permutation(NM)[:n_rows].astype(np.int32)
+        r[0] = 0  # the padding message among the rows: its new state must stay zero
+        rows = torch.from_numpy(np.sort(r)).cuda()
+    out = []
+    for fused in (True, False):
+        Z, P, Hn = (torch.full((NM, ld), 7.0, device="cuda") for _ in range(3))
+        if fused:
+            K.gru_update(S.data_ptr(), G.data_ptr(), ld, Wz.data_ptr(), Wh.data_ptr(), ld, Pz.data_ptr(), Ph.data_ptr(),
+                         ld, wid.data_ptr(), K.ptr(rows), n_rows, Z.data_ptr(), P.data_ptr(), Hn.data_ptr(), H, 0)
+        else:
+            K.gemm_nt(S.data_ptr(), ld, Wz.data_ptr(), ld, Z.data_ptr(), ld, n_rows, H, H, add=Pz.data_ptr(), ld_add=ld,
+                      add_idx=wid.data_ptr(), act=K.ACT_SIGMOID, a_rows=K.ptr(rows), c_rows=K.ptr(rows))
+            K.gemm_nt(G.data_ptr(), ld, Wh.data_ptr(), ld, P.data_ptr(), ld, n_rows, H, H, add=Ph.data_ptr(), ld_add=ld,
+                      add_idx=wid.data_ptr(), mode=K.EPI_GRU_BLEND, aux0=Z.data_ptr(), aux1=S.data_ptr(),
+                      out2=Hn.data_ptr(), ld_aux=ld, a_rows=K.ptr(rows), c_rows=K.ptr(rows), zero_row=0)
+        torch.cuda.synchronize()
+        out.append((Z.cpu().numpy(), P.cpu().numpy(), Hn.cpu().numpy()))
+    for a, b, what in zip(out[0], out[1], "zph"):
+        assert np.array_equal(a, b), what
+    sel = rows.cpu().numpy() if with_rows else np.arange(n_rows)
+    Sn, Gn = S.cpu().numpy().astype(np.float64)[:, :H], G.cpu().numpy().astype(np.float64)[:, :H]
+    w = wid.cpu().numpy()
+    z = 1 / (1 + np.exp(-(Sn[sel] @ Wz.cpu().numpy().astype(np.float64)[:, :H].T + Pz.cpu().numpy()[w[sel]][:, :H])))
+    p = np.tanh(Gn[sel] @ Wh.cpu().numpy().astype(np.float64)[:, :H].T + Ph.cpu().numpy()[w[sel]][:, :H])
+    h = (1 - z) * Sn[sel] + z * p
+    h[sel == 0] = 0
+    assert rel_err(out[0][0][sel][:, :H], z) < 1e-5 and rel_err(out[0][1][sel][:, :H], p) < 1e-5
+    assert rel_err(out[0][2][sel][:, :H], h) < 1e-5
+    assert not out[0][2][sel][:, H:].any()  # padding columns written as zero
+    untouched = np.setdiff1d(np.arange(NM), sel)
+    assert (out[0][2][untouched] == 7.0).all()  # rows outside the list are not written
