@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 7
+#define JTVAE_ABI_VERSION 8
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -162,6 +162,8 @@ int jtvae_copy_rows(const float* src, int32_t ld_src, float* dst, int32_t ld_dst
 /* out[i] = sum_{e in [rowptr[i], rowptr[i+1])} src(col[e])        for i < n_rows
  *   src(j) = src0[j]            if j <  n_src0
  *          = src1[j - n_src0]   otherwise          (src1 == NULL: single source)
+ *   relu_src != 0: rows of the last source (src1 if given, else src0) are pre-activations and enter the
+ *   sum as max(row, 0) (message = relu(binput), mpn.py:88 / jtmpn.py:90, without storing the activated copy)
  *   then, in this order:  if relu_mask:  out[i] *= (relu_mask[i] > 0)
  *                         if accumulate: out[i] += previous out[i]
  *                         if acc2:       acc2[i] += out[i]
@@ -173,7 +175,7 @@ int jtvae_copy_rows(const float* src, int32_t ld_src, float* dst, int32_t ld_dst
 int jtvae_csr_gather_sum(float* out, const float* src0, int32_t n_src0, const float* src1,
                          const int32_t* rowptr, const int32_t* col, int32_t n_rows, int32_t H,
                          int32_t ld, const float* relu_mask, int32_t accumulate, float* acc2,
-                         void* stream);
+                         int32_t relu_src, void* stream);
 
 /* Per-segment mean readout: out[b] = (1/len_b) * sum rows[start_b : start_b+len_b]
  * (fast_jtnn/mpn.py:103-107, fast_jtnn/jtmpn.py:105-110).  seg = int32 [n_seg,2] (start,len). */

@@ -11,15 +11,22 @@ using namespace jtvae;
 
 namespace {
 
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+}
+
 template <bool TWO_SRC>
 __global__ __launch_bounds__(JTVAE_BLOCK) void csr_gather_sum_kernel(
     float* __restrict__ out, const float* __restrict__ src0, int n_src0, const float* __restrict__ src1,
     const int* __restrict__ rowptr, const int* __restrict__ col, long total, int h4, int H, int ld,
-    const float* __restrict__ relu_mask, int accumulate, float* __restrict__ acc2) {
+    const float* __restrict__ relu_mask, int accumulate, float* __restrict__ acc2, int relu_src) {
   RowPos p = row_pos(total, h4);
   if (!p.ok) return;
   int beg = rowptr[p.row], end = rowptr[p.row + 1];
   float4 acc = f4zero();
+  // relu_src: the rows of the LAST source (src1 if given, else src0) hold pre-activations; their ReLU is
+  // taken as they are read, so the activated copy never has to be written
+  const bool relu0 = relu_src && !TWO_SRC;
   // four independent row loads in flight per thread
   for (int e = beg; e < end; e += 4) {
     int j[4];
@@ -30,10 +37,13 @@ __global__ __launch_bounds__(JTVAE_BLOCK) void csr_gather_sum_kernel(
     for (int u = 0; u < 4; ++u) {
       v[u] = f4zero();
       if (j[u] >= 0) {
-        if (TWO_SRC && j[u] >= n_src0)
+        if (TWO_SRC && j[u] >= n_src0) {
           v[u] = *rowp(src1, j[u] - n_src0, ld, p.c4);
-        else
+          if (relu_src) v[u] = relu4(v[u]);
+        } else {
           v[u] = *rowp(src0, j[u], ld, p.c4);
+          if (relu0) v[u] = relu4(v[u]);
+        }
       }
     }
 #pragma unroll
@@ -257,7 +267,7 @@ extern "C" {
 
 int jtvae_csr_gather_sum(float* out, const float* src0, int32_t n_src0, const float* src1,
                          const int32_t* rowptr, const int32_t* col, int32_t n_rows, int32_t H, int32_t ld,
-                         const float* relu_mask, int32_t accumulate, float* acc2, void* stream) {
+                         const float* relu_mask, int32_t accumulate, float* acc2, int32_t relu_src, void* stream) {
   if (n_rows < 0 || H <= 0 || H > ld || n_src0 < 0) return JTVAE_E_SHAPE;
   if (n_rows == 0) return 0;
   if (!rowptr || !col) return JTVAE_E_NULL;
@@ -271,10 +281,10 @@ int jtvae_csr_gather_sum(float* out, const float* src0, int32_t n_src0, const fl
   hipStream_t s = (hipStream_t)stream;
   if (src1)
     hipLaunchKernelGGL(csr_gather_sum_kernel<true>, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, s, out, src0,
-                       n_src0, src1, rowptr, col, total, h4, H, ld, relu_mask, accumulate, acc2);
+                       n_src0, src1, rowptr, col, total, h4, H, ld, relu_mask, accumulate, acc2, relu_src);
   else
     hipLaunchKernelGGL(csr_gather_sum_kernel<false>, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, s, out, src0,
-                       n_src0, src1, rowptr, col, total, h4, H, ld, relu_mask, accumulate, acc2);
+                       n_src0, src1, rowptr, col, total, h4, H, ld, relu_mask, accumulate, acc2, relu_src);
   return launch_status();
 }
 

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class Epilogue(C.Structure):
@@ -102,7 +102,7 @@ SIGNATURES = {
     "jtvae_prep_decoder_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
     "jtvae_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
-    "jtvae_csr_gather_sum": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "jtvae_csr_gather_sum": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp]),
     "jtvae_segment_mean": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_segment_mean_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_gru_iter0": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -323,12 +323,13 @@ def copy_rows(src, ld_src, dst, ld_dst, nrows, ncols):
 
 
 def csr_gather_sum(out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask=None, accumulate=False,
-                   acc2=None, nnz=None):
+                   acc2=None, nnz=None, relu_src=False):
     row_b = 4 * H
     extra = (1 if relu_mask else 0) + (1 if accumulate else 0) + (2 if acc2 else 0)
     nbytes = 0 if nnz is None else (nnz + n_rows * (1 + extra)) * row_b + 4 * (n_rows + 1 + nnz)
     _run("csr_gather_sum", lib.jtvae_csr_gather_sum,
-         (out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask, int(accumulate), acc2, stream_ptr()),
+         (out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask, int(accumulate), acc2, int(relu_src),
+          stream_ptr()),
          nbytes=nbytes)
 
 

@@ -142,23 +142,25 @@ class _GraphMPNFunction(torch.autograd.Function):
             tree = as_row_buffer(tree_message, H, ld)
         src0 = tree.data_ptr() if TM else None  # single-source gathers read the bond rows as src0
 
-        def gather(out, msg, csr, n_rows):
+        def gather(out, msg, csr, n_rows, pre_act):
+            # pre_act: `msg` holds binput; message 0 = relu(binput) is formed as the rows are read
             if TM:
                 K.csr_gather_sum(out.data_ptr(), src0, TM, msg.data_ptr(), csr.rowptr.data_ptr(),
-                                 csr.col.data_ptr(), n_rows, H, ld, nnz=csr.nnz)
+                                 csr.col.data_ptr(), n_rows, H, ld, nnz=csr.nnz, relu_src=pre_act)
             else:
                 K.csr_gather_sum(out.data_ptr(), msg.data_ptr(), NB, None, csr.rowptr.data_ptr(),
-                                 csr.col.data_ptr(), n_rows, H, ld, nnz=csr.nnz)
+                                 csr.col.data_ptr(), n_rows, H, ld, nnz=csr.nnz, relu_src=pre_act)
 
         binput = K.rows(NB, ld, dev)
-        msgs = [K.rows(NB, ld, dev)]
-        # binput = W_i fbonds; message = relu(binput)            (mpn.py:87-88)
-        K.gemm_nt(P.fbonds.data_ptr(), P.fbonds.stride(0), Wi.data_ptr(), Wi.stride(0), msgs[0].data_ptr(), ld,
-                  NB, H, fb_dim, act=K.ACT_RELU, pre_out=binput.data_ptr(), ld_pre=ld)
+        # binput = W_i fbonds; message 0 = relu(binput) is never stored: its readers take the ReLU themselves
+        # and the backward mask (message > 0) is binput > 0                                    (mpn.py:87-88)
+        K.gemm_nt(P.fbonds.data_ptr(), P.fbonds.stride(0), Wi.data_ptr(), Wi.stride(0), binput.data_ptr(), ld,
+                  NB, H, fb_dim)
+        msgs = [binput]
         neis = []
         for _ in range(depth - 1):  # mpn.py:90-94
             nei = K.rows(NB, ld, dev)
-            gather(nei, msgs[-1], P.bcsr, NB)
+            gather(nei, msgs[-1], P.bcsr, NB, msgs[-1] is binput)
             new = K.rows(NB, ld, dev)
             K.gemm_nt(nei.data_ptr(), ld, Wh.data_ptr(), ld, new.data_ptr(), ld, NB, H, H,
                       add=binput.data_ptr(), ld_add=ld, act=K.ACT_RELU)
@@ -168,7 +170,7 @@ class _GraphMPNFunction(torch.autograd.Function):
                 msgs = msgs[-1:]
                 neis = []
         anei = K.rows(NA, ld, dev)  # mpn.py:96-99
-        gather(anei, msgs[-1], P.acsr, NA)
+        gather(anei, msgs[-1], P.acsr, NA, msgs[-1] is binput)
         ah = K.rows(NA, ld, dev)
         K.gemm_nt(P.fatoms.data_ptr(), P.fatoms.stride(0), Woa.data_ptr(), Woa.stride(0), ah.data_ptr(), ld,
                   NA, H, fa_dim, bias=W_o_b.detach().data_ptr())

@@ -249,6 +249,22 @@ def test_csr_gather_sum_variants(K, H):
     want = ref * (mask > 0) + prev
     assert rel_err(outd[:, :H].cpu().numpy(), want) < 1e-6
     assert rel_err(acc2d[:, :H].cpu().numpy(), acc2 + want) < 1e-6
+    # ReLU taken on read: of the second source only when there are two, of the only source otherwise
+    for two in (True, False):
+        act = np.concatenate([s0, np.maximum(s1, 0)]) if two else np.maximum(cat, 0)
+        ref_r = np.zeros((n_rows, H), dtype=np.float64)
+        for i in range(n_rows):
+            for e in range(rp[i], rp[i + 1]):
+                ref_r[i] += act[col[e]]
+        o = torch.empty((n_rows, ld), device="cuda")
+        if two:
+            K.csr_gather_sum(o.data_ptr(), dev_rows(s0, ld).data_ptr(), n0, dev_rows(s1, ld).data_ptr(), rpd.data_ptr(),
+                             cold.data_ptr(), n_rows, H, ld, relu_src=True)
+        else:
+            K.csr_gather_sum(o.data_ptr(), dev_rows(cat, ld).data_ptr(), n0 + n1, None, rpd.data_ptr(), cold.data_ptr(),
+                             n_rows, H, ld, relu_src=True)
+        torch.cuda.synchronize()
+        assert rel_err(o[:, :H].cpu().numpy(), ref_r) < 1e-6
 
 
 def test_segment_mean_and_backward(K):
