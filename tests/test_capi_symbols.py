@@ -35,7 +35,7 @@ def test_argument_checks_happen_before_launch():
     assert lib.jtvae_gemm_nt(16, 4, 16, 4, 16, 4, -1, 4, 4, None, None) == -2
     assert lib.jtvae_gemm_nt(16, 2, 16, 4, 16, 4, 8, 4, 4, None, None) == -2  # lda < K
     assert lib.jtvae_csr_gather_sum(16, 16, 1, None, 16, 16, 4, 450, 450, None, 0, None, 0, None) == -3  # ld % 4
-    assert lib.jtvae_csr_gather_sum(16, 20, 1, None, 16, 16, 4, 450, 452, None, 0, None, None) == -3  # base
+    assert lib.jtvae_csr_gather_sum(16, 20, 1, None, 16, 16, 4, 450, 452, None, 0, None, 0, None) == -3  # base
     assert lib.jtvae_gru_iter0(None, None, None, None, None, None, 4, 450, 452, 0, None) == -1
     assert lib.jtvae_gemm_tn(16, 452, None, 16, 452, None, 16, 450, None, 100, 450, 450, 0, 16, 8, None) == -5  # workspace
     assert lib.jtvae_gemm_tn_workspace_bytes(100000, 450, 450) > 0
