@@ -123,7 +123,7 @@ int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const floa
 
 /* jtvae_gemm_tn without a workspace argument and without any allocation: the slab partials go to a
  * fixed array in device memory that the library holds on every GPU it runs on until the process
- * ends (jtvae_gemm_tn_static_max_bytes() = 48 MiB: enough for every N, K <= 450 product at any M).
+ * ends (jtvae_gemm_tn_static_max_bytes() = 64 MiB: enough for every N, K <= 450 product at any M).
  * It has no counterpart in the reference; it is for callers that cannot allocate (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same slab plan as
  * jtvae_gemm_tn, so results are bit-identical to it.  A product whose partials need more than the

@@ -55,10 +55,10 @@ extern "C" __device__ unsigned long long* jtvae_trace_buf = nullptr;  // [blocks
 #endif
 
 // Slab partials of jtvae_gemm_tn_static: a fixed array in device memory, one copy per GPU, held for
-// the life of the process.  48 MiB holds the partials of every N, K <= 450 product for any M (at most
-// 52 slabs of 450 x 452 floats).  In host code `tn_scratch` is only a handle for the symbol: the
+// the life of the process.  64 MiB holds the partials of every N, K <= 450 product for any M (at most
+// 64 slabs of 450 x 452 floats).  In host code `tn_scratch` is only a handle for the symbol: the
 // address a kernel may use comes from hipGetSymbolAddress, once per device.
-constexpr size_t TN_SCRATCH_BYTES = (size_t)48 << 20;
+constexpr size_t TN_SCRATCH_BYTES = (size_t)64 << 20;
 constexpr int TN_MAX_DEVICES = 64;
 static __device__ __align__(256) unsigned char tn_scratch[TN_SCRATCH_BYTES];
 static void* tn_scratch_ptr[TN_MAX_DEVICES];
@@ -799,18 +799,21 @@ __device__ __forceinline__ float4 mask4_ones(float4 v, bool row_ok, int k, int K
   return v;
 }
 
-// NACC = 32-column accumulators per wave: 3 (k tile 96) for the square products, 2 / 1 when the reduced-over
-// operand is a narrow feature matrix (K + bias column <= 64 / 32): no MFMA is spent on padding columns.
+// NACC = 32-column accumulators per wave (k tile 32 * NACC): 3..5 for the wide products, whichever pads K least,
+// 2 / 1 when the reduced-over operand is a narrow feature matrix (K + bias column <= 64 / 32): no MFMA is spent
+// on padding columns.
 template <bool VEC, int NACC>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
+__global__ __launch_bounds__(256, NACC >= 4 ? 3 : 2) void gemm_tn_kernel(TnArgs a) {
   constexpr int BKK = 32 * NACC;  // k tile
   constexpr int Y4 = 8 * NACC;    // float4 per staged Y row
   __shared__ __attribute__((aligned(16))) float Xs[TN_BM * TN_BN];
   __shared__ __attribute__((aligned(16))) float Ys[TN_BM * BKK];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles = a.tiles_n * a.tiles_k;
-  const int split = blockIdx.x / tiles;
-  const int tile = blockIdx.x % tiles;
+  // the tiles of one slab re-read the slab's X and Y rows: keep them on one XCD so that its L2 serves the re-reads
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = bid / tiles;
+  const int tile = bid % tiles;
   const int n0 = (tile / a.tiles_k) * TN_BN;
   const int k0 = (tile % a.tiles_k) * BKK;
   const int m_beg = split * a.rows_per_split;
@@ -903,20 +906,40 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   }
 }
 
-// sums the slab partials in slab order; column K (present when dbias is given) goes to dbias
+// sums the slab partials in slab order; column K (present when dbias is given) goes to dbias.  A thread owns
+// four consecutive columns of one row and keeps eight slabs' loads in flight; the additions stay in slab order.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ P, int splits, int N, int K,
                                                           int ldp, float* __restrict__ dW, int lddw,
                                                           float* __restrict__ dbias, int accumulate) {
   const int Kx = K + (dbias ? 1 : 0);
+  const int quads = (Kx + 3) >> 2;
   long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (long)N * Kx) return;
-  int n = (int)(gid / Kx), k = (int)(gid - (long)n * Kx);
-  const float* p = P + (size_t)n * ldp + k;
+  if (gid >= (long)N * quads) return;
+  const int n = (int)(gid / quads), k = 4 * (int)(gid - (long)n * quads);
+  const float* p = P + (size_t)n * ldp + k;  // ldp % 4 == 0 and the slabs are 16-byte aligned
   const size_t stride = (size_t)N * ldp;
-  float acc = 0.f;
-  for (int s = 0; s < splits; ++s) acc += p[s * stride];
-  float* o = k < K ? dW + (size_t)n * lddw + k : dbias + n;
-  *o = accumulate ? *o + acc : acc;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int s = 0;
+  for (; s + 8 <= splits; s += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ld4(p + (size_t)(s + j) * stride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w;
+    }
+  }
+  for (; s < splits; ++s) {
+    float4 v = ld4(p + (size_t)s * stride);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (k + j >= Kx) break;
+    float* o = k + j < K ? dW + (size_t)n * lddw + k + j : dbias + n;
+    *o = accumulate ? *o + r[j] : r[j];
+  }
 }
 
 inline bool aligned16(const void* p, int ld) { return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ld & 3) == 0); }
@@ -930,12 +953,28 @@ struct TnPlan {
 };
 inline TnPlan tn_plan(int M, int N, int K, int ones_col) {
   TnPlan p;
-  p.nacc = K + ones_col <= 32 ? 1 : (K + ones_col <= 64 ? 2 : 3);
+  const int kk = K + ones_col;
+  if (kk <= 64) {
+    p.nacc = kk <= 32 ? 1 : 2;
+  } else {  // widest k tile among those that pad the k extent least: more MFMAs per byte staged
+    int best = 0;
+    p.nacc = 3;
+    for (int n = 5; n >= 3; --n) {
+      int padded = (kk + 32 * n - 1) / (32 * n) * (32 * n);
+      if (!best || padded < best) { best = padded; p.nacc = n; }
+    }
+    // a product too short to fill the chip with wide tiles runs on more, shorter-lived blocks instead
+    const int wide_tiles = ((N + TN_BN - 1) / TN_BN) * (best / (32 * p.nacc));
+    if (p.nacc > 3 && (M + 255) / 256 < 768 / wide_tiles) p.nacc = 3;
+  }
   p.tiles_n = (N + TN_BN - 1) / TN_BN;
-  p.tiles_k = (K + ones_col + 32 * p.nacc - 1) / (32 * p.nacc);
+  p.tiles_k = (kk + 32 * p.nacc - 1) / (32 * p.nacc);
   int tiles = p.tiles_n * p.tiles_k;
   int want = (M + 255) / 256;               // at least 256 rows per slab
-  int cap = (1024 + tiles - 1) / tiles;     // about four blocks per CU in total
+  // every block does the same work, so the grid is sized to what the chip holds at once (256 CUs x the blocks
+  // a CU keeps resident) and never a few blocks more: those would run alone behind a full round
+  int resident = 256 * (p.nacc <= 3 ? 4 : 3);
+  int cap = resident / tiles;
   int s = want < cap ? want : cap;
   if (s < 1) s = 1;
   int rows = (M + s - 1) / s;
@@ -1071,14 +1110,15 @@ int gemm_tn_run(const float* X, int32_t ldx, const int32_t* x_rows, const float*
     else                                                                                        \
       hipLaunchKernelGGL((gemm_tn_kernel<false, NACC>), dim3(blocks), dim3(256), 0, s, a);      \
   } while (0)
-  if (p.nacc == 1)
-    JTVAE_TN_LAUNCH(1);
-  else if (p.nacc == 2)
-    JTVAE_TN_LAUNCH(2);
-  else
-    JTVAE_TN_LAUNCH(3);
+  switch (p.nacc) {
+    case 1: JTVAE_TN_LAUNCH(1); break;
+    case 2: JTVAE_TN_LAUNCH(2); break;
+    case 3: JTVAE_TN_LAUNCH(3); break;
+    case 4: JTVAE_TN_LAUNCH(4); break;
+    default: JTVAE_TN_LAUNCH(5); break;
+  }
 #undef JTVAE_TN_LAUNCH
-  long total = (long)N * (K + ones_col);
+  long total = (long)N * ((K + ones_col + 3) / 4);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.P, p.splits, N,
                      K, p.ldp, dW, lddw, dbias, accumulate);
   return launch_status();
