@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 8
+#define JTVAE_ABI_VERSION 9
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -299,6 +299,18 @@ int jtvae_prep_stable_from(const int32_t* rowptr, const int32_t* col, int64_t n,
  * gradients): order = item ids sorted by key, ties in input order; keyptr: [n_keys+1]. */
 int jtvae_prep_group_by_key(const int32_t* keys, int64_t n, int64_t n_keys, int32_t* keyptr,
                             int32_t* order);
+
+/* Backward plan of the compute-once GraphGRU schedule (the autograd backward of fast_jtnn/jtnn_enc.py:107-128
+ * restated so that every gradient-carrying message is visited once).  rowptr / col: the messages each message
+ * reads; seeds: messages with a gradient from outside the recurrence (n_seeds < 0: all of them).  Out: act [n]
+ * (1 = carries gradient: a seed, or read by a message that does); order: those messages by (level, rows that read
+ * something first, id), where level = 0 if no such message reads it, else 1 + the largest level among those
+ * readers; lev_off [levels+1]; per level n_dep (rows that read something), deg_sum (entries they read), tdeg_sum
+ * (readers among the visited messages).  Arrays need room for n (+1) entries.  counts[2] = {messages, levels}.
+ * JTVAE_E_RANGE: an index is out of range or the dependencies have a cycle. */
+int jtvae_prep_backward_once(const int32_t* rowptr, const int32_t* col, int64_t n, const int32_t* seeds,
+                             int64_t n_seeds, uint8_t* act, int32_t* order, int32_t* lev_off, int32_t* n_dep,
+                             int64_t* deg_sum, int64_t* tdeg_sum, int64_t* counts);
 
 /* Index form of the teacher-forced decoder traces of a batch (fast_jtnn/jtnn_dec.py:59-167, dfs :299-305),
  * from the junction-tree tables: directed edge m runs src[m] -> dst[m] (ids 1 .. n_mess-1 in the numbering of

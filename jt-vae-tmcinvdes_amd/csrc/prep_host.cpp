@@ -253,4 +253,89 @@ int jtvae_prep_decoder_plan(const int32_t* src, const int32_t* dst, int64_t n_me
   return 0;
 }
 
+// Backward plan of the compute-once tree-GRU schedule (each message visited once, fast_jtnn/jtnn_enc.py:107-128
+// differentiated): which messages carry gradient, their reverse dependency level and the visiting order.
+//   rowptr / col: the messages each message reads; seeds: messages with an outside gradient (n_seeds < 0: all).
+//   act[m] = 1 when m is a seed or is read by a message with act = 1.
+//   level of an active message = 0 when no active message reads it, else 1 + the largest level among its active
+//   readers: its gradient is complete once every lower level has been visited.
+//   order: the active messages by (level, rows that read something first, message id); lev_off[L] .. lev_off[L+1]
+//   delimit level L.  Per level: n_dep = rows that read something, deg_sum = entries they read, tdeg_sum = active
+//   readers of its rows.  counts = {active messages, levels}.
+int jtvae_prep_backward_once(const int32_t* rowptr, const int32_t* col, int64_t n, const int32_t* seeds,
+                             int64_t n_seeds, uint8_t* act, int32_t* order, int32_t* lev_off, int32_t* n_dep,
+                             int64_t* deg_sum, int64_t* tdeg_sum, int64_t* counts) {
+  if (n < 0) return JTVAE_E_SHAPE;
+  if (!rowptr || !act || !order || !lev_off || !n_dep || !deg_sum || !tdeg_sum || !counts) return JTVAE_E_NULL;
+  const int64_t nnz = n > 0 ? rowptr[n] : 0;
+  if (nnz > 0 && !col) return JTVAE_E_NULL;
+  if (n_seeds > 0 && !seeds) return JTVAE_E_NULL;
+  for (int64_t e = 0; e < nnz; ++e)
+    if (col[e] < 0 || col[e] >= n) return JTVAE_E_RANGE;
+  std::vector<int32_t> stack;
+  if (n_seeds < 0) {
+    std::memset(act, 1, (size_t)n);
+  } else {
+    std::memset(act, 0, (size_t)n);
+    for (int64_t i = 0; i < n_seeds; ++i) {
+      const int32_t m = seeds[i];
+      if (m < 0 || m >= n) return JTVAE_E_RANGE;
+      if (!act[m]) { act[m] = 1; stack.push_back(m); }
+    }
+    while (!stack.empty()) {
+      const int32_t r = stack.back();
+      stack.pop_back();
+      for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e)
+        if (!act[col[e]]) { act[col[e]] = 1; stack.push_back(col[e]); }
+    }
+  }
+  // active readers still to be visited, per message; a message is released when that count reaches zero
+  std::vector<int32_t> pending((size_t)n, 0), level((size_t)n, 0), ready;
+  for (int64_t r = 0; r < n; ++r)
+    if (act[r])
+      for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) ++pending[(size_t)col[e]];
+  std::vector<int32_t> tdeg(pending);  // active readers of every message
+  ready.reserve((size_t)n);
+  int64_t n_act = 0;
+  for (int64_t m = 0; m < n; ++m)
+    if (act[m]) {
+      ++n_act;
+      if (pending[(size_t)m] == 0) ready.push_back((int32_t)m);
+    }
+  int32_t max_level = -1;
+  for (size_t head = 0; head < ready.size(); ++head) {
+    const int32_t r = ready[head];
+    if (level[(size_t)r] > max_level) max_level = level[(size_t)r];
+    for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+      const int32_t m = col[e];
+      if (level[(size_t)m] < level[(size_t)r] + 1) level[(size_t)m] = level[(size_t)r] + 1;
+      if (--pending[(size_t)m] == 0) ready.push_back(m);
+    }
+  }
+  if ((int64_t)ready.size() != n_act) return JTVAE_E_RANGE;  // a dependency cycle: no compute-once order exists
+  const int64_t n_lev = (int64_t)max_level + 1;
+  // counting sort by (level, reads nothing), stable in message order
+  std::vector<int64_t> start((size_t)(2 * n_lev + 1), 0);
+  for (int64_t m = 0; m < n; ++m)
+    if (act[m]) ++start[(size_t)(2 * level[(size_t)m] + (rowptr[m + 1] == rowptr[m] ? 1 : 0)) + 1];
+  for (int64_t k = 0; k < 2 * n_lev; ++k) start[(size_t)k + 1] += start[(size_t)k];
+  for (int64_t L = 0; L < n_lev; ++L) {
+    lev_off[L] = (int32_t)start[(size_t)(2 * L)];
+    n_dep[L] = (int32_t)(start[(size_t)(2 * L + 1)] - start[(size_t)(2 * L)]);
+    deg_sum[L] = 0;
+    tdeg_sum[L] = 0;
+  }
+  lev_off[n_lev] = (int32_t)n_act;
+  for (int64_t m = 0; m < n; ++m)
+    if (act[m]) {
+      const int32_t L = level[(size_t)m];
+      order[start[(size_t)(2 * L + (rowptr[m + 1] == rowptr[m] ? 1 : 0))]++] = (int32_t)m;
+      deg_sum[L] += rowptr[m + 1] - rowptr[m];
+      tdeg_sum[L] += tdeg[(size_t)m];
+    }
+  counts[0] = n_act;
+  counts[1] = n_lev;
+  return 0;
+}
+
 }  // extern "C"

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class Epilogue(C.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
     "jtvae_prep_transpose_csr": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_stable_from": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "jtvae_prep_backward_once": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jtvae_prep_decoder_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
     "jtvae_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
@@ -197,8 +198,9 @@ class KernelTimer:
 
     active = None
 
-    def __init__(self):
+    def __init__(self, streams=False):
         self.records = []
+        self.streams = [] if streams else None  # stream handle of every record, for timelines
 
     def __enter__(self):
         KernelTimer.active = self
@@ -249,6 +251,8 @@ def _run(name, fn, args, nbytes=0, flops=0, tag=""):
     rc = fn(*args)
     e1.record()
     t.records.append((name, int(nbytes), int(flops), e0, e1, tag))
+    if t.streams is not None:
+        t.streams.append(torch.cuda.current_stream().cuda_stream)
     check(rc, name)
 
 
@@ -460,6 +464,34 @@ def prep_group_by_key(keys, n_keys):
         raise IndexError("key out of range [0, %d)" % n_keys)
     check(rc, "prep_group_by_key")
     return keyptr, order[:keys.size]
+
+
+def prep_backward_once(rowptr, col, seeds=None):
+    """Backward plan of the compute-once schedule (see jtvae_prep_backward_once): dict with act (bool [n]),
+    order, lev_off, n_dep, deg_sum, tdeg_sum (one entry per level)."""
+    import numpy as np
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    n = rowptr.size - 1
+    if seeds is not None:
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+    act = np.empty(max(n, 1), np.uint8)
+    order = np.empty(max(n, 1), np.int32)
+    lev_off = np.empty(n + 2, np.int32)
+    n_dep = np.empty(n + 1, np.int32)
+    deg_sum = np.empty(n + 1, np.int64)
+    tdeg_sum = np.empty(n + 1, np.int64)
+    counts = np.zeros(2, np.int64)
+    rc = lib.jtvae_prep_backward_once(_np_ptr(rowptr), _np_ptr(col), n, None if seeds is None else _np_ptr(seeds),
+                                      -1 if seeds is None else seeds.size, _np_ptr(act), _np_ptr(order),
+                                      _np_ptr(lev_off), _np_ptr(n_dep), _np_ptr(deg_sum), _np_ptr(tdeg_sum),
+                                      _np_ptr(counts))
+    if rc == E_RANGE:
+        raise IndexError("message dependencies are out of range or cyclic")
+    check(rc, "prep_backward_once")
+    n_act, n_lev = int(counts[0]), int(counts[1])
+    return dict(act=act[:n].view(np.bool_), order=order[:n_act], lev_off=lev_off[:n_lev + 1], n_dep=n_dep[:n_lev],
+                deg_sum=deg_sum[:n_lev], tdeg_sum=tdeg_sum[:n_lev])
 
 
 def prep_decoder_plan(src, dst, wid, roots):

@@ -673,19 +673,8 @@ def _expand_lists(rp: np.ndarray, col: np.ndarray, rows: np.ndarray) -> np.ndarr
     return col[idx]
 
 
-def _build_backward_schedule_once(sched: TreeSchedule, seeds: Optional[np.ndarray], wid_m: np.ndarray,
-                                  n_words: int, device) -> BackwardSchedule:
-    """Backward pass of the compute-once schedule: every message that carries gradient is visited once.
-
-    A message's total gradient is what its consumers outside the recurrence hand in plus what the
-    messages that read it pass back, so it is complete once all of those readers have been visited:
-    level 0 holds the messages no gradient-carrying message reads, level L those whose readers all sit
-    below L.  E[L] lists level L (rows that read other messages first: only they have products to
-    propagate), J[L] = E[L] for L >= 1 are the rows whose incoming gradient is gathered first.
-    """
-    h = sched._host
-    nm, sf = h["nm"], h["sf"]
-    m_rp, m_col, mt_rp, mt_col, deg = h["m_rp"], h["m_col"], h["mt_rp"], h["mt_col"], h["deg"]
+def backward_once_plan_np(m_rp, m_col, mt_rp, mt_col, deg, nm, seeds):
+    """numpy statement of K.prep_backward_once (its checker)."""
     act = np.zeros(nm, dtype=bool)
     if seeds is None:
         act[:] = True
@@ -712,36 +701,63 @@ def _build_backward_schedule_once(sched: TreeSchedule, seeds: Optional[np.ndarra
     # within a level: rows with inputs first, message order otherwise
     has_dep = deg[order] > 0
     order = order[np.lexsort((order, ~has_dep, rl[order]))]
-    lev_cnt = np.bincount(rl[order], minlength=max(n_lev, 1))[:max(n_lev, 1)]
-    lev_off = np.concatenate([[0], np.cumsum(lev_cnt)])
+    lev_cnt = np.bincount(rl[order], minlength=max(n_lev, 1))[:n_lev]
+    lev_off = np.concatenate([[0], np.cumsum(lev_cnt)]).astype(np.int64)
     tdeg_act = np.diff(f_rp)
-    El, Jl, offE, offJ, n_dep = [], [], [], [], []
+    lv = [order[lev_off[L]:lev_off[L + 1]] for L in range(n_lev)]
+    return dict(act=act, order=order, lev_off=lev_off, n_dep=np.asarray([int((deg[r] > 0).sum()) for r in lv]),
+                deg_sum=np.asarray([int(deg[r].sum()) for r in lv]),
+                tdeg_sum=np.asarray([int(tdeg_act[r].sum()) for r in lv]))
+
+
+def _dev_i64(a: np.ndarray, device) -> torch.Tensor:
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    if _TLS.upload is not None and _TLS.upload.device == torch.device(device) and a.size:
+        return _TLS.upload.add(a.view(np.int32)).view(torch.int64)  # chunks are 16-byte aligned
+    return _new_device_tensor(torch.from_numpy(a).to(device))
+
+
+def _build_backward_schedule_once(sched: TreeSchedule, seeds: Optional[np.ndarray], wid_m: np.ndarray,
+                                  n_words: int, device) -> BackwardSchedule:
+    """Backward pass of the compute-once schedule: every message that carries gradient is visited once.
+
+    A message's total gradient is what its consumers outside the recurrence hand in plus what the
+    messages that read it pass back, so it is complete once all of those readers have been visited:
+    level 0 holds the messages no gradient-carrying message reads, level L those whose readers all sit
+    below L.  E[L] lists level L (rows that read other messages first: only they have products to
+    propagate), J[L] = E[L] for L >= 1 are the rows whose incoming gradient is gathered first.
+    """
+    h = sched._host
+    deg = h["deg"]
+    plan = K.prep_backward_once(h["m_rp"], h["m_col"], seeds)
+    order = plan["order"].astype(np.int64)
+    lev_off, n_dep = plan["lev_off"], [int(v) for v in plan["n_dep"]]
+    n_lev = len(n_dep)
+    nE = int(order.size)
+    order_dev = _dev_i32(order, device) if nE else None  # one array; the levels are slices of it
+    El, Jl, offE, offJ = [], [], [], []
     nJ = 0
     for L in range(n_lev):
-        r = order[lev_off[L]:lev_off[L + 1]]
-        offE.append(int(lev_off[L]))
-        n_dep.append(int((deg[r] > 0).sum()))
-        rows_t = _dev_i32(r, device)
-        El.append(RowList(rows_t, int(r.size), int(deg[r].sum())))
+        a, b = int(lev_off[L]), int(lev_off[L + 1])
+        offE.append(a)
+        rows_t = order_dev[a:b]
+        El.append(RowList(rows_t, b - a, int(plan["deg_sum"][L])))
         if L == 0:
             Jl.append(RowList(None, 0))
             offJ.append(0)
         else:
-            Jl.append(RowList(rows_t, int(r.size), int(tdeg_act[r].sum())))
+            Jl.append(RowList(rows_t, b - a, int(plan["tdeg_sum"][L])))
             offJ.append(nJ)
-            nJ += int(r.size)
-    nE = int(order.size)
-    pos = np.arange(nE, dtype=np.int64)
+            nJ += b - a
     dep_rows = deg[order] > 0  # rows with s, g, t state: they contribute to the W_z / W_h products
-    zx, zy = pos[dep_rows], order[dep_rows]
-    lev0 = int(lev_cnt[0]) if n_lev else 0
+    zx, zy = np.flatnonzero(dep_rows), order[dep_rows]
+    lev0 = int(lev_off[1]) if n_lev else 0
     ux, uy = np.arange(nJ, dtype=np.int64), order[lev0:]
-    keys = wid_m[order]
-    kp, kc = _key_lists(keys.astype(np.int64), n_words, device)
+    kp, kc = _key_lists(wid_m[order], n_words, device)
     one = np.zeros(1, dtype=np.int64)
     return BackwardSchedule(
         E=El, J=Jl, offE=offE, offJ=offJ, nE=nE, nJ=nJ,
-        active=_new_device_tensor(torch.from_numpy(act.astype(np.int64)).to(device)),
+        active=_dev_i64(plan["act"].astype(np.int64), device),
         zx=_dev_i32(zx if zx.size else one, device), zy=_dev_i32(zy if zy.size else one, device), n_z=int(zx.size),
         ux=_dev_i32(ux if ux.size else one, device), uy=_dev_i32(uy if uy.size else one, device), n_u=int(ux.size),
         key_pieces=kp, key=kc, once=True, n_dep=n_dep)

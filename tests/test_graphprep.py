@@ -119,6 +119,32 @@ def test_compute_once_schedule_covers_every_message_exactly_once():
     assert G.build_tree_schedule(rp, col, trp, tcol, nm, shallow_T, "cpu", mode="once").mode == "level"
 
 
+def test_native_backward_plan_equals_its_numpy_statement():
+    """Backward plan of the compute-once schedule: the native single pass against the numpy statement, with all
+    messages seeded and with the root-feeding messages only; junction trees and an edge-free graph."""
+    from fast_jtnn_hip import _capi as K, synthetic, tensorize as T
+    cases = []
+    for seed, n_trees in ((3, 40), (4, 1), (5, 7)):
+        jt, _ = T.jtenc_tensorize(synthetic.make_batch(seed, n_trees, vocab_size=30))
+        mg, ng = jt[3].numpy(), jt[2].numpy()
+        roots = np.asarray([st for st, _ in jt[4]], dtype=np.int64)
+        cases.append((mg, G.padded_to_csr(ng[roots], mg.shape[0])[1]))
+    cases.append((np.zeros((5, 2), dtype=np.int64), np.array([2, 4], dtype=np.int32)))
+    for mg, root_mess in cases:
+        nm = mg.shape[0]
+        rp, col = G.padded_to_csr(mg, nm)
+        trp, tcol = G.transpose_csr(rp, col, nm)
+        deg = np.diff(rp).astype(np.int64)
+        for seeds in (None, root_mess, root_mess[:1], root_mess[:0]):
+            got = K.prep_backward_once(rp, col, seeds)
+            want = G.backward_once_plan_np(rp.astype(np.int64), col.astype(np.int64), trp.astype(np.int64),
+                                           tcol.astype(np.int64), deg, nm, seeds)
+            for k in ("act", "order", "lev_off", "n_dep", "deg_sum", "tdeg_sum"):
+                assert np.array_equal(np.asarray(got[k]).astype(np.int64), np.asarray(want[k]).astype(np.int64)), k
+    with pytest.raises(IndexError):  # a cycle has no compute-once order
+        K.prep_backward_once(np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32), None)
+
+
 def test_native_decoder_plan_equals_the_walk_over_tree_objects():
     """Trace tables of the teacher-forced decoder: the native walk over the junction-tree holder against the
     plain-Python walk over the tree objects (encoder numbering of the messages), field by field."""
