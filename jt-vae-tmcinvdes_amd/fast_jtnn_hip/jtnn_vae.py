@@ -12,8 +12,6 @@ step can be repeated exactly (tests, N-rank == 1-rank checks).
 """
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -127,10 +125,7 @@ class JTNNVAE(nn.Module):
         cache = self.__dict__.setdefault("_stream_cache", {})
         key = (device.type, device.index)
         if key not in cache:
-            # the tree encoder is a chain of short dependent launches: on a high-priority stream its blocks are
-            # placed ahead of the graph encoder's long-running ones whenever a CU has room
-            prio = int(os.environ.get("JTVAE_TREE_STREAM_PRIORITY", "-1"))
-            cache[key] = (torch.cuda.Stream(device=device, priority=prio), torch.cuda.Stream(device=device))
+            cache[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
         return cache[key]
 
     def encode(self, jtenc_holder, mpn_holder):  # jtnn_vae.py:45-48
@@ -143,16 +138,10 @@ class JTNNVAE(nn.Module):
         cur = torch.cuda.current_stream(device)
         s_tree.wait_stream(cur)
         s_graph.wait_stream(cur)
-        if os.environ.get("JTVAE_GRAPH_FIRST", "0") == "1":
-            with torch.cuda.stream(s_graph):
-                mol_vecs = self.mpn(*mpn_holder)
-            with torch.cuda.stream(s_tree):
-                tree_vecs, tree_mess = self.jtnn(*jtenc_holder)
-        else:
-            with torch.cuda.stream(s_tree):
-                tree_vecs, tree_mess = self.jtnn(*jtenc_holder)
-            with torch.cuda.stream(s_graph):
-                mol_vecs = self.mpn(*mpn_holder)
+        with torch.cuda.stream(s_tree):
+            tree_vecs, tree_mess = self.jtnn(*jtenc_holder)
+        with torch.cuda.stream(s_graph):
+            mol_vecs = self.mpn(*mpn_holder)
         cur.wait_stream(s_tree)
         cur.wait_stream(s_graph)
         for t in (tree_vecs, tree_mess, mol_vecs):  # allocated on a side stream, consumed on the caller's

@@ -171,3 +171,66 @@ def test_broadcast_gradients_reach_the_kernels():
     for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
         if q.grad is not None:
             assert torch.equal(p.grad, q.grad), n
+
+
+def test_full_training_step_at_batch_4096_is_the_mean_of_its_halves():
+    """The full-step configuration (4096 molecules per GPU, JTNNVAE.forward + backward + clip + Adam through
+    the trainer).  No CPU oracle finishes this size in seconds, so the check is the path's linearity: every
+    loss term is a sum over molecules divided by the batch size (fast_jtnn/jtnn_vae.py:85-103, 137;
+    jtnn_dec.py:183-190), hence loss and gradients of the batch are the means of those of its two halves."""
+    from fast_jtnn_hip import synthetic, tensorize as T, trainer
+
+    B, V = 4096, 385
+    trees = synthetic.make_batch(4242, B, vocab_size=V, mean_atoms=40.0, with_cands=True)
+
+    def x_batch(part):
+        synthetic.set_batch_nodeID(part)
+        jt, mess_dict = T.jtenc_tensorize(part)
+        mp = T.mpn_tensorize([t.mol for t in part])
+        cands, bi = synthetic.collect_candidates(part)
+        return part, jt, mp, (T.jtmpn_tensorize(cands, mess_dict), torch.from_numpy(bi))
+
+    class G:
+        pass
+    g = G()
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = 7, B, 450, 56, 20, 3, V, 0.05
+    m = make_hip_model(g, "cuda")
+    rs = np.random.RandomState(5)
+    eps = [torch.from_numpy(rs.standard_normal((B, 28)).astype(np.float32)).cuda() for _ in range(2)]
+    beta = 0.005
+
+    def run(lo, hi):
+        m.zero_grad(set_to_none=True)
+        out = m(x_batch(trees[lo:hi]), beta, epsilons=[e[lo:hi] for e in eps])
+        out[0].backward()
+        torch.cuda.synchronize()
+        return ([float(out[0].item()), float(out[1])] + [float(v) for v in out[2:]],
+                {n: p.grad.detach().clone() for n, p in m.named_parameters()})
+
+    full, g_full = run(0, B)
+    a, g_a = run(0, B // 2)
+    b, g_b = run(B // 2, B)
+    assert all(np.isfinite(full))
+    assert close(full[0], 0.5 * (a[0] + b[0]), 1e-5) and close(full[1], 0.5 * (a[1] + b[1]), 1e-5)
+    for name, gf in g_full.items():
+        mean = 0.5 * (g_a[name] + g_b[name])
+        err = float((gf - mean).norm() / mean.norm().clamp_min(1e-30))
+        assert err < 1e-4, (name, err)
+
+    # one iteration of the training loop on the whole batch: same loss, clipped gradient, first Adam step
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    tr = trainer.Trainer(m, trainer.Schedule(beta=beta, print_iter=10 ** 9, save_iter=10 ** 9, anneal_iter=10 ** 9,
+                                             kl_anneal_iter=10 ** 9), log=lambda *a: None)
+    res = tr.step(x_batch(trees), epsilons=eps)
+    assert res.ok and close(res.loss, full[0], 1e-5)
+    total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in g_full.values())))
+    moved = 0
+    for name, p in m.named_parameters():
+        assert torch.isfinite(p).all(), name
+        # the gradient in the bucket is the full-batch gradient scaled by the clip factor
+        scale = min(1.0, 50.0 / (total + 1e-6))
+        assert float((p.grad - scale * g_full[name]).norm() / (scale * g_full[name]).norm().clamp_min(1e-30)) < 1e-4, name
+        step = (p.detach() - before[name]).abs().max().item()
+        assert step <= 1e-3 * 1.001  # Adam's first step moves every weight by at most the learning rate
+        moved += step > 0
+    assert moved == len(before)
