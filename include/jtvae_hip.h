@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 9
+#define JTVAE_ABI_VERSION 10
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -78,6 +78,12 @@ typedef struct jtvae_epilogue {
 } jtvae_epilogue_t;
 
 int jtvae_abi_version(void);
+
+/* Number of kernels jtvae_gemm_nt, jtvae_gemm_nt_pair and jtvae_gru_update have launched from the calling host
+ * thread so far.  A pair or a fused update that does not fit its one-launch form (row counts, alignment) runs as
+ * two launches; per-launch measurements read this counter before and after a call.  No counterpart in the
+ * reference. */
+uint64_t jtvae_nt_launch_count(void);
 const char* jtvae_error_string(int code);
 
 /* ---- dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) ------------- */

@@ -1072,8 +1072,13 @@ int nt_setup(const float* A, int32_t lda, const float* W, int32_t ldw, float* C,
   return 0;
 }
 
+// NT-family kernels launched by this host thread so far: a call that cannot take its fused form runs as two
+// launches, and whoever prices a call per launch (a profiler's view) can ask how many it made
+thread_local unsigned long long nt_launches = 0;
+
 // picks the kernel for one product by its row count and operand alignment
 void launch_nt_any(const NtArgs& a, bool vec, hipStream_t s) {
+  ++nt_launches;
   if (vec && a.M <= SM_MAX_ROWS && a.K <= SM_KMAX)
     launch_nt_small(a, s);
   else if (vec && a.evec && a.M <= narrow_max_rows())
@@ -1177,6 +1182,7 @@ int jtvae_gemm_nt_pair(const jtvae_gemm_nt_problem_t* p0, const jtvae_gemm_nt_pr
     b.n_blocks = ((b.M + 31) / 32) * b.n_tiles_n;
     hipLaunchKernelGGL((gemm_nt_small_pair_kernel<JTVAE_EPI_PLAIN, JTVAE_EPI_MUL_ACC>), dim3(a.n_blocks + b.n_blocks),
                        dim3(256), 0, s, a, b);
+    ++nt_launches;
   } else if (combo && a.evec && b.evec && big <= narrow_max_rows()) {
     a.n_tiles_n = (a.N + 31) / 32;
     a.n_blocks = ((a.M + NT_BM - 1) / NT_BM) * a.n_tiles_n;
@@ -1184,6 +1190,7 @@ int jtvae_gemm_nt_pair(const jtvae_gemm_nt_problem_t* p0, const jtvae_gemm_nt_pr
     b.n_blocks = ((b.M + NT_BM - 1) / NT_BM) * b.n_tiles_n;
     hipLaunchKernelGGL((gemm_nt_pair_kernel<JTVAE_EPI_PLAIN, JTVAE_EPI_MUL_ACC, 1>), dim3(a.n_blocks + b.n_blocks),
                        dim3(256), 0, s, a, b);
+    ++nt_launches;
   } else {
     if (p0->M > 0) launch_nt_any(a, vec_a, s);
     if (p1->M > 0) launch_nt_any(b, vec_b, s);
@@ -1218,6 +1225,7 @@ int jtvae_gru_update(const float* S, const float* G, int32_t ld, const float* Wz
   a.ld = ld; a.ldw = ldw; a.ldp = ldp;
   a.M = n_rows; a.N = H; a.K = H; a.zero_row = zero_row;
   a.n_tiles_n = (H + 31) / 32;
+  ++nt_launches;
   if (n_rows <= SM_MAX_ROWS) {
     a.n_blocks = ((n_rows + 31) / 32) * a.n_tiles_n;
     hipLaunchKernelGGL(gru_update_small_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
@@ -1261,6 +1269,8 @@ int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, con
 }
 
 int jtvae_abi_version(void) { return JTVAE_ABI_VERSION; }
+
+uint64_t jtvae_nt_launch_count(void) { return nt_launches; }
 
 const char* jtvae_error_string(int code) {
   switch (code) {

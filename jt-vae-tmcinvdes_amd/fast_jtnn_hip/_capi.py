@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class Epilogue(C.Structure):
@@ -98,6 +98,7 @@ SIGNATURES = {
     "jtvae_prep_padded_to_csr": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _i64, C.POINTER(C.c_int64)]),
     "jtvae_prep_transpose_csr": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_stable_from": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "jtvae_nt_launch_count": (C.c_uint64, []),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_backward_once": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jtvae_prep_decoder_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
@@ -214,9 +215,9 @@ class KernelTimer:
         """kernel -> dict(launches, ms, bytes, flops); synchronises once."""
         torch.cuda.synchronize()
         out = OrderedDict()
-        for name, nbytes, flops, e0, e1, _tag in self.records:
+        for name, nbytes, flops, e0, e1, _tag, n in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0, flops=0))
-            d["launches"] += 1
+            d["launches"] += n
             d["ms"] += e0.elapsed_time(e1)
             d["bytes"] += nbytes
             d["flops"] += flops
@@ -226,9 +227,9 @@ class KernelTimer:
         """(kernel, shape tag) -> dict(launches, ms, bytes, flops)."""
         torch.cuda.synchronize()
         out = OrderedDict()
-        for name, nbytes, flops, e0, e1, tag in self.records:
+        for name, nbytes, flops, e0, e1, tag, n in self.records:
             d = out.setdefault((name, tag), dict(launches=0, ms=0.0, bytes=0, flops=0))
-            d["launches"] += 1
+            d["launches"] += n
             d["ms"] += e0.elapsed_time(e1)
             d["bytes"] += nbytes
             d["flops"] += flops
@@ -247,10 +248,13 @@ def _run(name, fn, args, nbytes=0, flops=0, tag=""):
         return
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
+    before = lib.jtvae_nt_launch_count() if name == "gemm_nt" else 0
     e0.record()
     rc = fn(*args)
     e1.record()
-    t.records.append((name, int(nbytes), int(flops), e0, e1, tag))
+    # a pair / fused update that had to run as two launches counts as two
+    n = max(1, lib.jtvae_nt_launch_count() - before) if name == "gemm_nt" else 1
+    t.records.append((name, int(nbytes), int(flops), e0, e1, tag, n))
     if t.streams is not None:
         t.streams.append(torch.cuda.current_stream().cuda_stream)
     check(rc, name)

@@ -83,7 +83,8 @@ def traffic(root, steps_total):
 
 def sq(root, steps_total):
     T, C = load(root + "/pmc_SQ/*/*_counter_collection.csv")
-    kernels = sorted({k for c in T.values() for k in c})
+    ours = {k for _, ks in ENTRY for k in ks if k != "|"}  # the library's kernels; torch's own are left out
+    kernels = sorted({k for c in T.values() for k in c} & ours)
     out = {}
     for k in kernels:
         v = {c: T[c].get(k, 0.0) for c in T}

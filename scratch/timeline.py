@@ -28,5 +28,5 @@ n = len(kt.records) // 7
 recs = kt.records[-n:]; strs = kt.streams[-n:]
 ids = {s: i for i, s in enumerate(dict.fromkeys(strs))}
 print("step: %.3f ms (base -> end), %d launches" % (base.elapsed_time(end), n))
-for (name, nb, fl, e0, e1, tag), s in zip(recs, strs):
+for (name, nb, fl, e0, e1, tag, _n), s in zip(recs, strs):
     print("%9.1f %8.1f s%d %-18s %s" % (1e3 * base.elapsed_time(e0), 1e3 * e0.elapsed_time(e1), ids[s], name, tag))
