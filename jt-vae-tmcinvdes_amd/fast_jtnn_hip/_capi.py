@@ -399,14 +399,15 @@ def segment_ce(scores, seg_ptr, label_pos, n_seg, loss_seg, hit_seg, dscores, n_
                                               stream_ptr()), nbytes=8 * n_scores + 16 * n_seg)
 
 
-def row_dot(score, q, owner, cand, n_cand, H, ld):
+def row_dot(score, q, owner, cand, n_cand, H, ld, n_owner=None):
+    # an owner's row is shared by its consecutive candidates: priced once per owner, not once per candidate
     _run("row_dot", lib.jtvae_row_dot, (score, q, owner, cand, n_cand, H, ld, stream_ptr()),
-         nbytes=4 * H * 2 * n_cand + 8 * n_cand)
+         nbytes=4 * H * (n_cand + (n_cand if n_owner is None else n_owner)) + 8 * n_cand)
 
 
 def row_dot_bwd(dscore, q, owner, cand, own_ptr, n_cand, n_owner, dq, dcand, H, ld):
     _run("row_dot_bwd", lib.jtvae_row_dot_bwd, (dscore, q, owner, cand, own_ptr, n_cand, n_owner, dq, dcand, H, ld,
-                                                stream_ptr()), nbytes=4 * H * (3 * n_cand + n_owner) + 12 * n_cand)
+                                                stream_ptr()), nbytes=4 * H * (2 * n_cand + 2 * n_owner) + 12 * n_cand)
 
 
 # ---- host-side index preparation (numpy arrays in host memory; no GPU involved) -----------------

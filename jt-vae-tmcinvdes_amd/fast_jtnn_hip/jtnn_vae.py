@@ -74,7 +74,8 @@ class _RowDot(torch.autograd.Function):
         with torch.cuda.device(q.device):
             qp, cp = as_row_buffer(q, H, ld), as_row_buffer(cand, H, ld)
             score = torch.empty((cand.shape[0],), dtype=torch.float32, device=q.device)
-            K.row_dot(score.data_ptr(), qp.data_ptr(), owner.data_ptr(), cp.data_ptr(), cand.shape[0], H, ld)
+            K.row_dot(score.data_ptr(), qp.data_ptr(), owner.data_ptr(), cp.data_ptr(), cand.shape[0], H, ld,
+                      n_owner=q.shape[0])
         ctx.keep = (qp, cp, owner, own_ptr, H, ld)
         return score
 

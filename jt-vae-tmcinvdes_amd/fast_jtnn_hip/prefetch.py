@@ -123,3 +123,10 @@ class Prefetcher:
                 pass
             self.thread.join(timeout=0.05)
         self.pool.shutdown(wait=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

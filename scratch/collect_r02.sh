@@ -9,6 +9,7 @@ for w in "train 1024" "encode 1024" "encode 4096" "train_assm 1024" "train_full 
   set -- $w
   bash $R/scratch/profile_r02.sh $1 $2 all || exit 1
 done
+bash $R/scratch/profile_r02.sh train 1024 stats1 || exit 1
 echo profiled
 exit 0
 fi

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes over one bench workload: kernel trace + stats, then one --pmc pass per counter group.
-#   scratch/profile_r02.sh MODE BATCH [stats|pmc|all]
+#   scratch/profile_r02.sh MODE BATCH [stats|stats1|pmc|all]
 # Outputs under gpurun_out/r02_<mode>_<batch>/; the summaries to keep are copied to profiles/ afterwards.
 MODE=${1:-train}; BATCH=${2:-1024}; WHAT=${3:-all}
 cd /tmp; export TMPDIR=/tmp
@@ -11,6 +11,11 @@ if [ $WHAT = stats ] || [ $WHAT = all ]; then
   D=$OUT/stats; rm -rf $D; mkdir -p $D
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --mode $MODE --batch $BATCH --steps 10 --warmup 3 --no-cpu-baseline --no-fresh-holders > $D/bench.json 2> $D/bench.err || { tail -5 $D/bench.err; exit 1; }
   cp $D/*/*_kernel_stats.csv $OUT/kernel_stats.csv || exit 1
+fi
+if [ $WHAT = stats1 ]; then  # the same command on one stream: per-kernel durations free of co-running kernels
+  D=$OUT/stats1; rm -rf $D; mkdir -p $D
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 $R/bench.py --mode $MODE --batch $BATCH --steps 10 --warmup 3 --no-overlap --no-cpu-baseline --no-fresh-holders > $D/bench.json 2> $D/bench.err || { tail -5 $D/bench.err; exit 1; }
+  cp $D/*/*_kernel_stats.csv $OUT/kernel_stats_one_stream.csv || exit 1
 fi
 if [ $WHAT = pmc ] || [ $WHAT = all ]; then
   for c in FETCH_SIZE WRITE_SIZE SQ; do

@@ -84,9 +84,8 @@ def test_prefetched_holders_give_bitwise_the_same_step():
         return out
 
     direct = run(batches())
-    pf = Prefetcher(batches(), lambda b: warm_training_batch(model, b), "cuda:0", depth=2)
-    ahead = run(pf)
-    pf.close()
+    with Prefetcher(batches(), lambda b: warm_training_batch(model, b), "cuda:0", depth=2) as pf:
+        ahead = run(pf)
     assert len(direct) == len(ahead) == 5
     again = run(batches())
     for (la, ga), (lb, gb), (lc, gc) in zip(direct, ahead, again):
