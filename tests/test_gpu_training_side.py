@@ -234,3 +234,34 @@ def test_full_training_step_at_batch_4096_is_the_mean_of_its_halves():
         assert step <= 1e-3 * 1.001  # Adam's first step moves every weight by at most the learning rate
         moved += step > 0
     assert moved == len(before)
+
+
+def test_training_cli_writes_checkpoints_the_oracle_model_loads(tmp_path):
+    """train.py end to end (the reference's loop, fast_molvae/vae_train.py:97-146, under its flag names): prints the
+    reference's progress lines, anneals, and saves state dicts whose keys and shapes are the reference model's."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, "train.py"), "--train", "synthetic:192:3", "--vocab", "60", "--save_dir",
+         str(tmp_path), "--batch_size", "64", "--epoch", "2", "--print_iter", "2", "--save_iter", "4", "--warmup", "2",
+         "--kl_anneal_iter", "2", "--anneal_iter", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "[2] Loss:" in out.stdout and "learning rate: 0.000900" in out.stdout
+    names = sorted(os.listdir(tmp_path))
+    assert "model.iter-4" in names and "model.epoch-6" in names
+    state = torch.load(os.path.join(tmp_path, "model.epoch-6"), map_location="cpu", weights_only=True)
+
+    class G:
+        pass
+    g = G()
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = 0, 64, 450, 56, 20, 3, 60, 0.0
+    ora = make_oracle_vae(g)
+    want = ora.state_dict()
+    assert set(state) == set(want)
+    for k, v in want.items():
+        assert tuple(state[k].shape) == tuple(v.shape), k
+        assert torch.isfinite(state[k]).all(), k
+    ora.load_state_dict(state)
