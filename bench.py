@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Encoder fwd+bwd throughput on synthetic molecular graphs (the second configuration of
-BASELINE.json: 1024 molecules of ~40 atoms, <=6 neighbours, MPN depth 3 + tree GRU depth 20,
-hidden 450, latent 56, per GPU).
+"""Encoder fwd+bwd throughput on synthetic molecular graphs (1024 molecules of ~40 atoms, <=6 neighbours,
+MPN depth 3 + tree GRU depth 20, hidden 450, latent 56, per GPU).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \

@@ -99,10 +99,13 @@ def shard_by_cost(costs: Sequence[float], world: int) -> List[List[int]]:
 
 
 class FlatGradBucket:
-    """All gradients of a module as views into one contiguous buffer.
+    """The gradients of a module, joined in one contiguous buffer for the collective.
 
-    ``zero()`` before backward, ``all_reduce_mean()`` after it.  Autograd adds into
-    the views, so no gather/scatter copies surround the collective.
+    ``zero()`` before backward drops the gradients (``.grad = None``): autograd then hands every parameter the
+    tensor its backward produced, instead of adding it into a zeroed buffer - one add kernel per parameter and
+    the fill are saved.  ``all_reduce_mean()`` after backward: with more than one rank the gradients are packed
+    into the flat buffer by one copy launch, reduced by ONE collective, and ``.grad`` of every parameter becomes
+    a view of the reduced buffer; with one rank nothing is copied at all.
     """
 
     def __init__(self, params: Sequence[torch.nn.Parameter]):
@@ -112,22 +115,32 @@ class FlatGradBucket:
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=dt, device=dev)
+        self.views = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
             off += n
 
     def zero(self) -> None:
-        self.flat.zero_()
-        for p in self.params:  # a caller may have replaced .grad (optimizer.zero_grad(set_to_none=True))
-            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
-                raise RuntimeError("a parameter's .grad no longer lives in the bucket; use bucket.zero() "
-                                   "instead of zero_grad(set_to_none=True)")
+        for p in self.params:
+            p.grad = None
+
+    def pack(self) -> None:
+        """Copy every gradient into its slot of the flat buffer (zeros where a parameter got none) and point
+        ``.grad`` at the slots."""
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            self.flat.zero_()
+        have = [(v, g) for v, g in zip(self.views, grads) if g is not None and g.data_ptr() != v.data_ptr()]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def all_reduce_mean(self) -> None:
         if dist.is_initialized() and dist.get_world_size() > 1:
+            self.pack()
             if self.flat.is_cuda and dist.get_backend() != "nccl" and _PRESYNC:
                 # A host-staged backend (gloo) copies the bucket to host memory from its own side stream;
                 # draining the launch stream first keeps that copy from queueing behind a whole backward pass.

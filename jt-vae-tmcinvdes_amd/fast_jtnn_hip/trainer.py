@@ -75,7 +75,7 @@ class Trainer:
                  total_step: int = 0, log=print):
         self.model, self.sched, self.save_dir, self.conditional = model, sched or Schedule(), save_dir, conditional
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.bucket = parallel.FlatGradBucket(self.params)  # .grad of every parameter lives in one buffer
+        self.bucket = parallel.FlatGradBucket(self.params)  # one buffer for the gradient all-reduce
         self.optimizer = torch.optim.Adam(self.params, lr=self.sched.lr)  # vae_train.py:73-74
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(self.optimizer, self.sched.anneal_rate)
         self.beta = self.sched.beta
@@ -98,7 +98,7 @@ class Trainer:
 
     def step(self, batch, epsilons=None) -> StepResult:
         self.total_step += 1
-        self.bucket.zero()  # model.zero_grad() of the reference, keeping the gradient views in place
+        self.bucket.zero()  # model.zero_grad() of the reference
         loss, metrics, err = None, {}, None
         try:
             loss, metrics = self.forward_backward(batch, epsilons)

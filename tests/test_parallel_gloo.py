@@ -62,7 +62,7 @@ def _worker(rank, world, port, out_dir):
     jt, mp_ = _build(trees[lo:hi])
     m = _model()
     bucket = parallel.FlatGradBucket([p for p in m.parameters() if p.requires_grad])
-    for _ in range(2):  # second pass checks that zero() really resets the views
+    for _ in range(2):  # second pass checks that zero() really drops the first pass's gradients
         bucket.zero()
         _loss(m, jt, mp_).backward()
         bucket.all_reduce_mean()
@@ -86,6 +86,7 @@ def test_two_ranks_equal_one_rank(tmp_path):
     bucket = parallel.FlatGradBucket([p for p in m.parameters() if p.requires_grad])
     bucket.zero()
     _loss(m, jt, mp_).backward()
+    bucket.pack()  # a single rank has no collective and leaves the gradients where autograd put them
     ref = bucket.flat.numpy()
     assert np.abs(a - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
 
@@ -102,12 +103,21 @@ def test_shard_helpers():
         parallel.shard_bounds(4, 2, 2)
 
 
-def test_bucket_detects_replaced_grads():
-    import pytest
+def test_bucket_packs_whatever_gradients_the_parameters_hold():
     lin = torch.nn.Linear(3, 2)
-    b = parallel.FlatGradBucket(list(lin.parameters()))
+    extra = torch.nn.Parameter(torch.zeros(4))  # takes no part in the loss: its slot must read zero
+    b = parallel.FlatGradBucket(list(lin.parameters()) + [extra])
+    b.flat.fill_(7.0)
+    b.zero()
+    assert all(p.grad is None for p in b.params)
     lin(torch.ones(1, 3)).sum().backward()
-    assert float(b.flat.abs().sum()) > 0
-    lin.zero_grad(set_to_none=True)
-    with pytest.raises(RuntimeError):
-        b.zero()
+    w_grad = lin.weight.grad.clone()
+    b.pack()
+    assert torch.equal(b.flat[:6].view(2, 3), w_grad) and torch.equal(b.flat[8:], torch.zeros(4))
+    assert lin.weight.grad.data_ptr() == b.flat.data_ptr()  # .grad now lives in the flat buffer
+    b.pack()  # packing twice is harmless
+    assert torch.equal(b.flat[:6].view(2, 3), w_grad)
+    lin.zero_grad(set_to_none=True)  # a caller's own reset is as good as zero()
+    lin(torch.ones(1, 3)).sum().backward()
+    b.pack()
+    assert torch.equal(b.flat[:6].view(2, 3), w_grad)
