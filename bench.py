@@ -286,7 +286,7 @@ def main():
     from fast_jtnn_hip import parallel
 
     # N > 1 without a launcher: start the ranks as children before this process touches the GPU
-    parallel.self_launch_if_needed(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+    parallel.self_launch_if_needed(os.path.abspath(__file__), sys.argv[1:], args.gpus, json_only=True)
     if os.environ.get("JTVAE_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["JTVAE_BENCH_WATCHDOG"]), exit=True)

@@ -59,10 +59,13 @@ def launch_command(script: str, script_args: Sequence[str], n_procs: int, port: 
             "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(script_args)
 
 
-def self_launch_if_needed(script: str, script_args: Sequence[str], n_gpus: int) -> None:
+def self_launch_if_needed(script: str, script_args: Sequence[str], n_gpus: int, json_only: bool = False) -> None:
     """``python script --gpus N`` with N > 1 and no launcher environment: start the N ranks as child
     processes (before this process has touched the GPU), pass their output through and exit with their
-    return code.  Returns at once when N == 1 or when already running under a launcher."""
+    return code.  Returns at once when N == 1 or when already running under a launcher.
+
+    ``json_only``: the caller's contract is ONE JSON line on stdout; whatever else the ranks or the
+    communication library print there (connection banners) is passed to stderr instead."""
     import subprocess
     import sys
 
@@ -70,8 +73,15 @@ def self_launch_if_needed(script: str, script_args: Sequence[str], n_gpus: int) 
         return
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes here
-    res = subprocess.run(launch_command(script, script_args, n_gpus), env=env)
-    sys.exit(res.returncode)
+    cmd = launch_command(script, script_args, n_gpus)
+    if not json_only:
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        is_json = line.lstrip().startswith("{") and line.rstrip().endswith("}")
+        (sys.stdout if is_json else sys.stderr).write(line)
+        (sys.stdout if is_json else sys.stderr).flush()
+    sys.exit(proc.wait())
 
 
 def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:

@@ -118,3 +118,30 @@ def test_bench_and_trainer_start_their_own_ranks():
     assert cmd[cmd.index("--master-port") + 1] == "2345" and cmd[-5:] == ["/x/bench.py", "--gpus", "4", "--steps", "3"]
     os.environ.pop("WORLD_SIZE", None)
     parallel.self_launch_if_needed("/x/bench.py", [], 1)  # one GPU: returns without starting anything
+
+
+def test_self_launched_ranks_leave_one_json_line_on_stdout(tmp_path):
+    """The launcher form of ``bench.py --gpus N``: two ranks started by the parent, banners that the ranks (or
+    the communication library) write to stdout end up on stderr, the JSON line alone on stdout, and the
+    parent exits with the ranks' return code."""
+    import subprocess
+    import sys
+
+    script = tmp_path / "two_ranks.py"
+    script.write_text(
+        "import os, sys\n"
+        "print('[banner] rank %s up' % os.environ['RANK'], flush=True)\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    print('{\"value\": 1.5, \"n_gpus\": %s}' % os.environ['WORLD_SIZE'], flush=True)\n"
+        "sys.exit(3 if len(sys.argv) > 1 else 0)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys; sys.path.insert(0, %r); from fast_jtnn_hip import parallel; "
+            "parallel.self_launch_if_needed(%r, sys.argv[1:], 2, json_only=True)"
+            % (os.path.join(root, "jt-vae-tmcinvdes_amd"), str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    ok = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-1500:]
+    assert ok.stdout.strip() == '{"value": 1.5, "n_gpus": 2}'
+    assert "[banner] rank 0 up" in ok.stderr and "[banner] rank 1 up" in ok.stderr
+    bad = subprocess.run([sys.executable, "-c", prog, "fail"], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
