@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 10
+#define JTVAE_ABI_VERSION 11
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -255,6 +255,58 @@ int jtvae_gru_bwd_gather(const float* h, const float* Uh, size_t slab_stride, in
                          const float* dg, const float* ds, const int32_t* trowptr, const int32_t* tcol,
                          const int32_t* rows, int32_t n_rows, const float* dh_ext, float* dUh, float* dhdir,
                          int32_t H, int32_t ld, void* stream);
+
+/* ---- whole level sweeps of the compute-once schedule, one host call each ---------------------- */
+
+/* Levels 1 .. n_levels of GraphGRU.forward (jtnn_enc.py:110-127) with every message computed once, in the level
+ * in which it settles (level 0 is jtvae_gru_iter0).  All state buffers hold one row per message ([NM, ld]):
+ * h (in/out), uh = U_r h + b, s, g, t (NULL: inference), z, p.  Per level L: f_rows[L] / f_n[L] = device row
+ * list and count of the messages it updates, u_rows[L] / u_n[L] = the messages whose U_r product it needs first
+ * (those that settled in the level before and are read by someone); the arrays of pointers and counts live in
+ * HOST memory.  Pz / Pr / Ph: per-word tables [n_words, ld]; wid: table row of a message; rowptr / col: the
+ * messages each message reads; Wzh = W_z[:, H:], Whh = W_h[:, H:], Ur: [H, ld]; bu: [H] or NULL.  Issues, per
+ * level, jtvae_gemm_nt + jtvae_gru_gate_gather + jtvae_gru_update in that order: the result is bit-identical
+ * to issuing them one by one.  Stops at the first level with f_n == 0. */
+typedef struct jtvae_tree_fwd {
+  float *h, *uh, *s, *g, *t, *z, *p;
+  const int32_t* sf;
+  const float *Pz, *Pr, *Ph;
+  const int32_t* wid;
+  const int32_t *rowptr, *col;
+  const float *Wzh, *Whh, *Ur, *bu;
+  int32_t H, ld, pad_row, n_levels;
+  const int32_t* const* f_rows;
+  const int32_t* f_n;
+  const int32_t* const* u_rows;
+  const int32_t* u_n;
+} jtvae_tree_fwd_t;
+int jtvae_tree_gru_forward(const jtvae_tree_fwd_t* args, void* stream);
+
+/* The matching backward sweep (autograd of jtnn_enc.py:110-127 under the same schedule): every gradient-carrying
+ * message once, in the reverse dependency levels of jtvae_prep_backward_once.  e_rows[L] / e_n[L]: device row
+ * list and count of level L, n_dep[L]: its leading rows that read other messages, off_e[L] / off_j[L]: first
+ * compact row of the level in dz, dp / in du (host arrays).  dh: gradient of the final h by message id (in/out),
+ * dz, dp, du: compact outputs, ds, dg, dhdir: scratch by message id, a_r: accumulator by message id (zeroed by
+ * the caller), T: the iteration count of the forward pass, WzhT / WhhT / UrT: the transposed weight blocks.
+ * Issues, per level, jtvae_gru_bwd_gather + jtvae_gemm_nt (levels > 0), jtvae_gru_bwd_pointwise and
+ * jtvae_gemm_nt_pair, bit-identical to issuing them one by one. */
+typedef struct jtvae_tree_bwd {
+  const float *h, *uh, *s, *t, *z, *p;
+  const int32_t* sf;
+  const uint64_t* active;
+  const float* Pr;
+  const int32_t* wid;
+  const int32_t *trowptr, *tcol;
+  const float *WzhT, *WhhT, *UrT;
+  float *dh, *dz, *dp, *du, *ds, *dg, *dhdir, *a_r;
+  int32_t T, H, ld, pad_row, n_levels;
+  const int32_t* const* e_rows;
+  const int32_t* e_n;
+  const int32_t* n_dep;
+  const int64_t* off_e;
+  const int64_t* off_j;
+} jtvae_tree_bwd_t;
+int jtvae_tree_gru_backward(const jtvae_tree_bwd_t* args, void* stream);
 
 /* out[i] = slab sel[i] of base, row i: collects the final value of every message
  * (sel[i] = min(depth, sf[i])). */

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class Epilogue(C.Structure):
@@ -66,6 +66,23 @@ class NtProblem(C.Structure):
     ]
 
 
+class TreeFwd(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("h", "uh", "s", "g", "t", "z", "p", "sf", "Pz", "Pr", "Ph", "wid", "rowptr",
+                                            "col", "Wzh", "Whh", "Ur", "bu")] +
+                [(n, C.c_int32) for n in ("H", "ld", "pad_row", "n_levels")] +
+                [("f_rows", C.POINTER(C.c_void_p)), ("f_n", C.POINTER(C.c_int32)),
+                 ("u_rows", C.POINTER(C.c_void_p)), ("u_n", C.POINTER(C.c_int32))])
+
+
+class TreeBwd(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("h", "uh", "s", "t", "z", "p", "sf", "active", "Pr", "wid", "trowptr",
+                                            "tcol", "WzhT", "WhhT", "UrT", "dh", "dz", "dp", "du", "ds", "dg",
+                                            "dhdir", "a_r")] +
+                [(n, C.c_int32) for n in ("T", "H", "ld", "pad_row", "n_levels")] +
+                [("e_rows", C.POINTER(C.c_void_p)), ("e_n", C.POINTER(C.c_int32)), ("n_dep", C.POINTER(C.c_int32)),
+                 ("off_e", C.POINTER(C.c_int64)), ("off_j", C.POINTER(C.c_int64))])
+
+
 class PackItem(C.Structure):
     _fields_ = [
         ("src", C.c_void_p),
@@ -99,6 +116,8 @@ SIGNATURES = {
     "jtvae_prep_transpose_csr": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_stable_from": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "jtvae_nt_launch_count": (C.c_uint64, []),
+    "jtvae_tree_gru_forward": (C.c_int, [_vp, _vp]),
+    "jtvae_tree_gru_backward": (C.c_int, [_vp, _vp]),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_backward_once": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jtvae_prep_decoder_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
@@ -371,6 +390,26 @@ def gru_update(S, G, ld, Wz, Wh, ldw, Pz, Ph, ldp, wid, rows, n_rows, Z, P, Hout
                                            zero_row, stream_ptr()),
          nbytes=4 * (2 * n_rows * H + 2 * H * H + 4 * n_rows * H), flops=4 * n_rows * H * H,
          tag="gru_update M=%d N=%d K=%d" % (n_rows, H, H))
+
+
+def sweeps_enabled():
+    """The one-call level sweeps are used unless every launch is being timed or synchronised on its own."""
+    return KernelTimer.active is None and not _SYNC_EACH
+
+
+def row_list_arrays(lists):
+    """Host arrays (device pointers, counts) of a sequence of RowList-like objects (``ptr()``, ``n``)."""
+    ptrs = (C.c_void_p * len(lists))(*[r.ptr() for r in lists])
+    counts = (C.c_int32 * len(lists))(*[int(r.n) for r in lists])
+    return ptrs, counts
+
+
+def tree_gru_forward(args):
+    check(lib.jtvae_tree_gru_forward(C.byref(args), stream_ptr()), "tree_gru_forward")
+
+
+def tree_gru_backward(args):
+    check(lib.jtvae_tree_gru_backward(C.byref(args), stream_ptr()), "tree_gru_backward")
 
 
 def gru_bwd_pointwise(dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre, dppre, ds, H, ld, pad_row=0):

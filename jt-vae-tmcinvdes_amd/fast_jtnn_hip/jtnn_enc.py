@@ -75,6 +75,20 @@ class _TreeGRU:
             zs, ps, ss, gs, us = (torch.empty((1, NM, ld), dtype=torch.float32, device=dev) for _ in range(5))
             stride, sf_p, st = 0, None, {}
             K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, None, None, hs[0].data_ptr(), NM, H, ld, pad_row)
+        if compact and T > 1 and K.sweeps_enabled():
+            # all levels in one host call: the same launches in the same order as the loop below
+            lists = sched.__dict__.get("_fwd_lists")
+            if lists is None:
+                lists = sched.__dict__["_fwd_lists"] = (K.row_list_arrays(sched.F[1:T]), K.row_list_arrays(sched.U[1:T]))
+            (f_rows, f_n), (u_rows, u_n) = lists
+            a = K.TreeFwd(h=hs.data_ptr(), uh=us.data_ptr(), s=ss.data_ptr(), g=gs.data_ptr(),
+                          t=ts.data_ptr() if train else None, z=zs.data_ptr(), p=ps.data_ptr(), sf=sf_p,
+                          Pz=Pz.data_ptr(), Pr=Pr.data_ptr(), Ph=Ph.data_ptr(), wid=wid_p,
+                          rowptr=mcsr.rowptr.data_ptr(), col=mcsr.col.data_ptr(), Wzh=Wzh.data_ptr(),
+                          Whh=Whh.data_ptr(), Ur=Ur.data_ptr(), bu=None if bu is None else bu.data_ptr(), H=H, ld=ld,
+                          pad_row=pad_row, n_levels=T - 1, f_rows=f_rows, f_n=f_n, u_rows=u_rows, u_n=u_n)
+            K.tree_gru_forward(a)
+            return hs[0], st
         for t in range(1, T):
             F, U = sched.F[t], sched.U[t]
             if F.n == 0:
@@ -116,6 +130,22 @@ class _TreeGRU:
         a_r = K.rows(NM, ld, dev, zero=True)
         ds, dg, dhdir = K.rows(NM, ld, dev), K.rows(NM, ld, dev), K.rows(NM, ld, dev)
         wid_p = wid.data_ptr()
+        if bs.once and K.sweeps_enabled():
+            lists = bs.__dict__.get("_bwd_lists")
+            if lists is None:
+                n_lev = len(bs.E)
+                lists = bs.__dict__["_bwd_lists"] = K.row_list_arrays(bs.E) + (
+                    (K.C.c_int32 * n_lev)(*bs.n_dep), (K.C.c_int64 * n_lev)(*bs.offE), (K.C.c_int64 * n_lev)(*bs.offJ))
+            e_rows, e_n, n_dep, off_e, off_j = lists
+            a = K.TreeBwd(h=hs.data_ptr(), uh=us.data_ptr(), s=ss.data_ptr(), t=ts.data_ptr(), z=zs.data_ptr(),
+                          p=ps.data_ptr(), sf=sf_p, active=act_p, Pr=Pr.data_ptr(), wid=wid_p,
+                          trowptr=mcsr_t.rowptr.data_ptr(), tcol=mcsr_t.col.data_ptr(), WzhT=WzhT.data_ptr(),
+                          WhhT=WhhT.data_ptr(), UrT=UrT.data_ptr(), dh=dh.data_ptr(), dz=dz.data_ptr(),
+                          dp=dp.data_ptr(), du=du.data_ptr(), ds=ds.data_ptr(), dg=dg.data_ptr(),
+                          dhdir=dhdir.data_ptr(), a_r=a_r.data_ptr(), T=T, H=H, ld=ld, pad_row=pad_row,
+                          n_levels=len(bs.E), e_rows=e_rows, e_n=e_n, n_dep=n_dep, off_e=off_e, off_j=off_j)
+            K.tree_gru_backward(a)
+            return dz, dp, du, a_r
         if bs.once:
             # Every gradient-carrying message once, in reverse dependency order: when a level is reached all
             # messages that read its rows have been visited, so their gathered gradient is complete.  Saved

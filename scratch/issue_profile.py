@@ -25,4 +25,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(20): step()
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(35)
+pstats.Stats(pr).sort_stats("tottime").print_stats(25); pstats.Stats(pr).sort_stats("cumulative").print_stats(30)

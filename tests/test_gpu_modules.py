@@ -530,3 +530,46 @@ def test_one_deep_tree_in_a_batch_keeps_the_batch_on_the_compute_once_schedule()
     (tvo.sum() + (mso * mso).sum()).backward()
     for n, q in ora.named_parameters():
         assert fro_err(out["once"][2][n], q.grad.numpy()) < RTOL, n
+
+
+def test_one_call_level_sweeps_are_bitwise_the_launch_by_launch_form():
+    """jtvae_tree_gru_forward / _backward issue the launches of the level loop in the same order: outputs and
+    every gradient are bit-identical to the launch-by-launch form (which is what runs while launches are being
+    timed), with the gradient reaching all messages (through JTMPN) and with it reaching the roots only."""
+    from fast_jtnn_hip import _capi as K
+
+    g = Golden(CASES[2])
+    m = make_hip_model(g, "cuda")
+
+    def run(with_cands):
+        m.zero_grad(set_to_none=True)
+        if with_cands:
+            tv, ms, mv, cv = run_hip(g, m)
+            golden_loss(m, g, tv, mv, cv).backward()
+            outs = (tv, ms, mv, cv)
+        else:
+            mean, logvar = m.encode_latent(g.jtenc_holder(), g.mpn_holder())
+            (mean.sum() + (logvar * logvar).sum()).backward()
+            outs = (mean, logvar)
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], {n: p.grad.clone() for n, p in m.named_parameters()
+                                                    if p.grad is not None}
+
+    for with_cands in (True, False):
+        assert K.sweeps_enabled()
+        out_a, grad_a = run(with_cands)
+        with K.KernelTimer() as kt:
+            assert not K.sweeps_enabled()
+            out_b, grad_b = run(with_cands)
+        assert any(r[0] == "gru_gate_gather" for r in kt.records)  # the loop form really ran
+        for x, y in zip(out_a, out_b):
+            assert torch.equal(x, y)
+        assert set(grad_a) == set(grad_b) and any(n.startswith("jtnn.") for n in grad_a)
+        for n in grad_a:
+            assert torch.equal(grad_a[n], grad_b[n]), n
+    with torch.no_grad():  # inference form (no saved state)
+        a = [o.clone() for o in run_hip(g, m)]
+        with K.KernelTimer():
+            b = [o.clone() for o in run_hip(g, m)]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
