@@ -537,3 +537,23 @@ def test_gru_update_equals_the_two_products_it_replaces(K, n_rows, with_rows):
     assert not out[0][2][sel][:, H:].any()  # padding columns written as zero
     untouched = np.setdiff1d(np.arange(NM), sel)
     assert (out[0][2][untouched] == 7.0).all()  # rows outside the list are not written
+
+
+def test_level_sweeps_reject_bad_arguments_and_accept_an_empty_schedule(K):
+    """jtvae_tree_gru_forward / _backward: argument errors come back before any launch; a schedule without
+    levels (every message settled at iteration 0) is a no-op."""
+    import ctypes as C
+
+    assert K.lib.jtvae_tree_gru_forward(None, None) == K.E_NULL
+    assert K.lib.jtvae_tree_gru_backward(None, None) == K.E_NULL
+    f = K.TreeFwd(H=450, ld=452, n_levels=0)
+    assert K.lib.jtvae_tree_gru_forward(C.byref(f), K.stream_ptr()) == 0
+    b = K.TreeBwd(H=450, ld=452, n_levels=0, T=20)
+    assert K.lib.jtvae_tree_gru_backward(C.byref(b), K.stream_ptr()) == 0
+    f = K.TreeFwd(H=450, ld=448, n_levels=0)  # leading dimension shorter than a row
+    assert K.lib.jtvae_tree_gru_forward(C.byref(f), K.stream_ptr()) == K.E_SHAPE
+    f = K.TreeFwd(H=450, ld=452, n_levels=2)  # levels announced, no row lists
+    assert K.lib.jtvae_tree_gru_forward(C.byref(f), K.stream_ptr()) == K.E_NULL
+    b = K.TreeBwd(H=450, ld=452, n_levels=2, T=20)
+    assert K.lib.jtvae_tree_gru_backward(C.byref(b), K.stream_ptr()) == K.E_NULL
+    torch.cuda.synchronize()
