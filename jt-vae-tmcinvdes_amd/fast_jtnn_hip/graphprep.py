@@ -193,9 +193,12 @@ class packed_uploads:
 
 
 def _dev_i32(a: np.ndarray, device) -> torch.Tensor:
-    if a.size and int(a.max()) >= 2 ** 31:
-        raise OverflowError("index exceeds int32")
-    a = np.ascontiguousarray(a, dtype=np.int32)
+    if a.dtype != np.int32:  # an int32 array cannot overflow the conversion: no scan
+        if a.size and int(a.max()) >= 2 ** 31:
+            raise OverflowError("index exceeds int32")
+        a = a.astype(np.int32)
+    if not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a)
     if _TLS.upload is not None and _TLS.upload.device == torch.device(device):
         return _TLS.upload.add(a)
     return _new_device_tensor(torch.from_numpy(a).to(device))
@@ -345,6 +348,15 @@ def _key_lists(keys: np.ndarray, n_keys: int, device):
     return pieces, key_csr
 
 
+def _unique_bounded(ids: np.ndarray, bound: int):
+    """(sorted distinct values, position of every id among them) for ids in [0, bound): np.unique's result by
+    counting instead of sorting."""
+    seen = np.bincount(ids, minlength=bound) > 0
+    values = np.flatnonzero(seen)
+    rank = np.cumsum(seen) - 1
+    return values, rank[ids]
+
+
 def prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     with packed_uploads(device):
         return _prepare_tree(holder, device, vocab_size)
@@ -369,9 +381,8 @@ def _prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     rt_rp, rt_col = transpose_csr(r_rp, r_col, nm)
     nb = roots.shape[0]
 
-    words, inv = np.unique(fn, return_inverse=True)
+    words, wid_node = _unique_bounded(fn, vocab_size)
     nw = words.shape[0]
-    wid_node = inv.astype(np.int64)
     wid_m = wid_node[fm]
     wid_root = wid_node[roots]
     w_rp = np.arange(nw + 1, dtype=np.int64)
@@ -429,9 +440,8 @@ def prepare_message_dag(word_of_mess: np.ndarray, dep_rp: np.ndarray, dep_col: n
         m_col = np.ascontiguousarray(dep_col, dtype=np.int32)
         check_range(m_col, nm, "message dependencies")
         mt_rp, mt_col = transpose_csr(m_rp, m_col, nm)
-        words, inv = np.unique(wm, return_inverse=True)
+        words, wid_m = _unique_bounded(wm, vocab_size)
         nw = words.shape[0]
-        wid_m = inv.astype(np.int64)
         w_rp = np.arange(nw + 1, dtype=np.int64)
         wt_rp, wt_col = transpose_csr(w_rp.astype(np.int32), words.astype(np.int32), vocab_size)
         km_p, km = _key_lists(wid_m, nw, device)
