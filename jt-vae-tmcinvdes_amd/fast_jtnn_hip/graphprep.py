@@ -659,9 +659,9 @@ def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode, sf_tru
             # their current value in iteration t-1 and have readers
             r = np.flatnonzero((sf >= t) & (tdeg > 0))
             U.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size)))
-    host = dict(m_rp=np.asarray(m_rp, dtype=np.int64), m_col=np.asarray(m_col, dtype=np.int64),
-                mt_rp=np.asarray(mt_rp, dtype=np.int64), mt_col=np.asarray(mt_col, dtype=np.int64), sf=sf, nm=nm,
-                deg=deg.astype(np.int64), tdeg=tdeg.astype(np.int64))
+    # the CSR arrays stay as they came (int32): the backward plans widen what they index with, when they need to
+    host = dict(m_rp=m_rp, m_col=m_col, mt_rp=mt_rp, mt_col=mt_col, sf=sf, nm=nm, deg=deg.astype(np.int64),
+                tdeg=tdeg.astype(np.int64))
     return TreeSchedule(T=T, dense=dense, sf=_dev_i32(sf, device), sel_final=_dev_i32(np.minimum(sf, T), device),
                         F=F, U=U, bwd={}, _host=host, mode=mode)
 
@@ -740,7 +740,7 @@ def _build_backward_schedule_once(sched: TreeSchedule, seeds: Optional[np.ndarra
     h = sched._host
     deg = h["deg"]
     plan = K.prep_backward_once(h["m_rp"], h["m_col"], seeds)
-    order = plan["order"].astype(np.int64)
+    order = plan["order"]  # int32: uploaded as it is
     lev_off, n_dep = plan["lev_off"], [int(v) for v in plan["n_dep"]]
     n_lev = len(n_dep)
     nE = int(order.size)
@@ -760,11 +760,11 @@ def _build_backward_schedule_once(sched: TreeSchedule, seeds: Optional[np.ndarra
             offJ.append(nJ)
             nJ += b - a
     dep_rows = deg[order] > 0  # rows with s, g, t state: they contribute to the W_z / W_h products
-    zx, zy = np.flatnonzero(dep_rows), order[dep_rows]
+    zx, zy = np.flatnonzero(dep_rows).astype(np.int32), order[dep_rows]  # positions < nE <= nm: int32 holds them
     lev0 = int(lev_off[1]) if n_lev else 0
-    ux, uy = np.arange(nJ, dtype=np.int64), order[lev0:]
+    ux, uy = np.arange(nJ, dtype=np.int32), order[lev0:]
     kp, kc = _key_lists(wid_m[order], n_words, device)
-    one = np.zeros(1, dtype=np.int64)
+    one = np.zeros(1, dtype=np.int32)
     return BackwardSchedule(
         E=El, J=Jl, offE=offE, offJ=offJ, nE=nE, nJ=nJ,
         active=_dev_i64(plan["act"].astype(np.int64), device),
@@ -779,7 +779,7 @@ def _build_backward_schedule(sched: TreeSchedule, seeds: Optional[np.ndarray], w
         return _build_backward_schedule_once(sched, seeds, wid_m, n_words, device)
     h = sched._host
     nm, T, sf = h["nm"], sched.T, h["sf"]
-    m_rp, m_col, deg = h["m_rp"], h["m_col"], h["deg"]
+    m_rp, m_col, deg = np.asarray(h["m_rp"], dtype=np.int64), np.asarray(h["m_col"], dtype=np.int64), h["deg"]
     E = [None] * T
     use_mask = (not sched.dense) and T <= 63
     if sched.dense or not use_mask:
