@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 11
+#define JTVAE_ABI_VERSION 12
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -162,6 +162,12 @@ int jtvae_pack_batch(const jtvae_pack_item_t* items, int32_t n_items, void* stre
  * between torch's dense [rows, H] tensors and the padded row buffers. */
 int jtvae_copy_rows(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows,
                     int32_t cols, void* stream);
+
+/* dst[r, 0:cols] = (float)src[r, 0:cols] (src dense [rows, cols] bytes); dst columns [cols, ld_dst) = 0.
+ * The device half of shipping the one-hot feature rows (fast_jtnn/mpn.py:18-31, moved by create_var at
+ * mpn.py:82-85) as bytes; see jtvae_prep_features_to_u8. */
+int jtvae_widen_u8_rows(const uint8_t* src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols,
+                        void* stream);
 
 /* ---- neighbour gather-sum --------------------------------------------------------------- */
 
@@ -352,6 +358,11 @@ int jtvae_prep_transpose_csr(const int32_t* rowptr, const int32_t* col, int64_t 
 /* sf[m]: iteration from which message m of GraphGRU (jtnn_enc.py:107-128) no longer changes: 1 if
  * it reads no message, else 1 + max over the messages it reads, capped at max(T, 1). */
 int jtvae_prep_stable_from(const int32_t* rowptr, const int32_t* col, int64_t n, int32_t T, int32_t* sf);
+
+/* out[i] = (uint8_t)x[i] for i < n; *exact = 1 when every x[i] is a whole number in [0, 255] (the
+ * conversion loses nothing), else 0 and out is incomplete.  Replaces nothing in the reference, which moves
+ * the float rows as they are (nnutils.py:6-10 from mpn.py:82-85): it quarters the bytes of that move. */
+int jtvae_prep_features_to_u8(const float* x, int64_t n, uint8_t* out, int32_t* exact);
 
 /* Stable grouping by key (messages by the word of their source node, for the per-word table
  * gradients): order = item ids sorted by key, ties in input order; keyptr: [n_keys+1]. */

@@ -5,6 +5,7 @@
 // table; a transposed list holds its readers in increasing (row, slot) order.
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/jtvae_hip.h"
@@ -96,6 +97,59 @@ int jtvae_prep_stable_from(const int32_t* rowptr, const int32_t* col, int64_t n,
       }
     }
   }
+  return 0;
+}
+
+// Atom and bond feature rows are one-hot blocks (fast_jtnn/mpn.py:18-31): every value is a small
+// whole number, so the rows can cross the host-to-device link as bytes, a quarter of the float size,
+// and be widened again on the device without changing a bit.  One pass converts and checks; *exact
+// comes back 0 as soon as a value is not a whole number in [0, 255] (out is then incomplete and the
+// caller ships the floats).
+static bool features_to_u8_range(const float* x, int64_t b0, int64_t b1, uint8_t* out) {
+  constexpr int64_t BLOCK = 4096;  // mismatches are looked for per block, so the inner loop stays branch-free
+  for (int64_t b = b0; b < b1; b += BLOCK) {
+    const int64_t e = b + BLOCK < b1 ? b + BLOCK : b1;
+    int bad = 0;
+    for (int64_t i = b; i < e; ++i) {
+      const float v = x[i];
+      const uint8_t u = (uint8_t)(int32_t)(v >= 0.f && v <= 255.f ? v : 0.f);
+      const float w = (float)u;
+      uint32_t bv, bw;
+      std::memcpy(&bv, &v, 4);
+      std::memcpy(&bw, &w, 4);
+      out[i] = u;
+      bad |= bv != bw;  // NaN, -0, fractions, negatives and values above 255 all land here
+    }
+    if (bad) return false;
+  }
+  return true;
+}
+
+int jtvae_prep_features_to_u8(const float* x, int64_t n, uint8_t* out, int32_t* exact) {
+  if (n < 0) return JTVAE_E_SHAPE;
+  if (!exact || (n > 0 && (!x || !out))) return JTVAE_E_NULL;
+  // The pass streams 5 bytes per value and one core cannot saturate the memory system: large arrays (the bond
+  // rows of a few thousand molecules are ~10^7 values) are cut into up to 4 ranges converted side by side.
+  constexpr int64_t PER_THREAD = 1 << 21;
+  const int n_threads = (int)(n / PER_THREAD < 1 ? 1 : (n / PER_THREAD > 4 ? 4 : n / PER_THREAD));
+  if (n_threads == 1) {
+    *exact = features_to_u8_range(x, 0, n, out) ? 1 : 0;
+    return 0;
+  }
+  std::vector<std::thread> pool;
+  std::vector<char> ok((size_t)n_threads, 0);
+  const int64_t step = ((n + n_threads - 1) / n_threads + 4095) & ~(int64_t)4095;
+  for (int t = 1; t < n_threads; ++t) {
+    const int64_t b0 = t * step, b1 = b0 + step < n ? b0 + step : n;
+    pool.emplace_back([=, &ok] { ok[(size_t)t] = features_to_u8_range(x, b0 < n ? b0 : n, b1, out); });
+  }
+  ok[0] = features_to_u8_range(x, 0, step < n ? step : n, out);
+  bool all = ok[0];
+  for (int t = 1; t < n_threads; ++t) {
+    pool[(size_t)t - 1].join();
+    all = all && ok[(size_t)t];
+  }
+  *exact = all ? 1 : 0;
   return 0;
 }
 

@@ -122,6 +122,17 @@ __global__ __launch_bounds__(JTVAE_BLOCK) void copy_rows_kernel(const float* __r
   dst[gid] = c < cols ? src[r * ld_src + c] : 0.f;
 }
 
+// byte features widened to float rows, one thread per destination float (pads written as zero)
+__global__ __launch_bounds__(JTVAE_BLOCK) void widen_u8_rows_kernel(const uint8_t* __restrict__ src,
+                                                                    float* __restrict__ dst, int ld_dst,
+                                                                    long total, int cols) {
+  long gid = (long)blockIdx.x * JTVAE_BLOCK + threadIdx.x;
+  if (gid >= total) return;
+  long r = gid / ld_dst;
+  int c = (int)(gid - r * ld_dst);
+  dst[gid] = c < cols ? (float)src[r * cols + c] : 0.f;
+}
+
 // Several small matrices (the Linear weights of one module) packed or transposed into 16-byte-row
 // buffers by one launch: block b serves one 32 x 32 tile of one destination.  Padding columns of
 // every destination row are written as zero.
@@ -325,6 +336,17 @@ int jtvae_copy_rows(const float* src, int32_t ld_src, float* dst, int32_t ld_dst
   long total = (long)rows * ld_dst;
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, src,
                      ld_src, dst, ld_dst, total, cols);
+  return launch_status();
+}
+
+int jtvae_widen_u8_rows(const uint8_t* src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols,
+                        void* stream) {
+  if (rows < 0 || cols <= 0 || cols > ld_dst) return JTVAE_E_SHAPE;
+  if (rows == 0) return 0;
+  if (!src || !dst) return JTVAE_E_NULL;
+  long total = (long)rows * ld_dst;
+  hipLaunchKernelGGL(widen_u8_rows_kernel, dim3(grid_for(total)), dim3(JTVAE_BLOCK), 0, (hipStream_t)stream, src,
+                     dst, ld_dst, total, cols);
   return launch_status();
 }
 

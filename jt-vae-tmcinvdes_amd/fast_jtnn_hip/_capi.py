@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class Epilogue(C.Structure):
@@ -119,6 +119,8 @@ SIGNATURES = {
     "jtvae_tree_gru_forward": (C.c_int, [_vp, _vp]),
     "jtvae_tree_gru_backward": (C.c_int, [_vp, _vp]),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "jtvae_prep_features_to_u8": (C.c_int, [_vp, _i64, _vp, C.POINTER(C.c_int32)]),
+    "jtvae_widen_u8_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_prep_backward_once": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jtvae_prep_decoder_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
@@ -349,6 +351,11 @@ def copy_rows(src, ld_src, dst, ld_dst, nrows, ncols):
          nbytes=8 * nrows * ncols)
 
 
+def widen_u8_rows(src, dst, ld_dst, nrows, ncols):
+    _run("widen_u8_rows", lib.jtvae_widen_u8_rows, (src, dst, ld_dst, nrows, ncols, stream_ptr()),
+         nbytes=nrows * (ncols + 4 * ld_dst))
+
+
 def csr_gather_sum(out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask=None, accumulate=False,
                    acc2=None, nnz=None, relu_src=False):
     row_b = 4 * H
@@ -496,6 +503,14 @@ def prep_stable_from(rowptr, col, T):
     sf = np.empty(max(n, 1), dtype=np.int32)
     check(lib.jtvae_prep_stable_from(_np_ptr(rowptr), _np_ptr(col), n, int(T), _np_ptr(sf)), "prep_stable_from")
     return sf[:n]
+
+
+def prep_features_to_u8(x, out) -> bool:
+    """Float rows -> bytes in ``out`` (same element count); False when some value is not a whole number in
+    [0, 255] (``out`` is then incomplete)."""
+    exact = C.c_int32(0)
+    check(lib.jtvae_prep_features_to_u8(_np_ptr(x), x.size, _np_ptr(out), C.byref(exact)), "prep_features_to_u8")
+    return bool(exact.value)
 
 
 def prep_group_by_key(keys, n_keys):

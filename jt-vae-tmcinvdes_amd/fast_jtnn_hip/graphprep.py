@@ -210,11 +210,24 @@ def upload_csr(rowptr: np.ndarray, col: np.ndarray, device) -> DeviceCSR:
 
 
 def _upload_features(x: np.ndarray, device) -> torch.Tensor:
-    """[n, f] float32 -> device [n, round4(f)] with zero padding columns; the padding is added on the
-    device, so the host only hands over the array it already has."""
+    """[n, f] float32 -> device [n, round4(f)] with zero padding columns.
+
+    The rows are one-hot blocks (fast_jtnn/mpn.py:18-31).  When every value is a whole number in [0, 255] -
+    checked in the pass that converts them - they cross the link as bytes in pinned memory, a quarter of the
+    float size, and one kernel widens them into the padded rows: the same bits as shipping the floats.  Any
+    other content goes as floats and is padded on the device."""
     n, f = x.shape
     fp = (f + 3) // 4 * 4
-    src = _new_device_tensor(torch.from_numpy(np.ascontiguousarray(x)).to(device, non_blocking=True))
+    x = np.ascontiguousarray(x)
+    device = torch.device(device)
+    if n and device.type == "cuda":
+        stage = torch.empty((n, f), dtype=torch.uint8, pin_memory=True)
+        if K.prep_features_to_u8(x, stage.numpy()):
+            packed = stage.to(device, non_blocking=True)  # read by the next launch on this stream only
+            out = _new_device_tensor(torch.empty((n, fp), dtype=torch.float32, device=device))
+            K.widen_u8_rows(packed.data_ptr(), out.data_ptr(), fp, n, f)
+            return out
+    src = _new_device_tensor(torch.from_numpy(x).to(device, non_blocking=True))
     if fp == f:
         return src
     out = _new_device_tensor(torch.zeros((n, fp), dtype=torch.float32, device=device))
@@ -335,6 +348,22 @@ class TreePrep:
     host: dict = None  # numpy copies needed to build schedules lazily
     schedules: dict = None  # (T, dense) -> TreeSchedule
 
+    def ensure_training(self):
+        """The transposed adjacencies and the per-word groupings are only read by the backward pass: a holder
+        prepared for inference (they are None then) gets them on its first use under gradient mode."""
+        if self.mcsr_t is None:
+            h, dev = self.host, self.host["device"]
+            with packed_uploads(dev):
+                mt_rp, mt_col = transpose_csr(h["m_rp"], h["m_col"], self.n_mess)
+                h["mt_rp"], h["mt_col"] = mt_rp, mt_col
+                self.mcsr_t = upload_csr(mt_rp, mt_col, dev)
+                self.rcsr_t = upload_csr(*transpose_csr(h["r_rp"], h["r_col"], self.n_mess), dev)
+                w_rp = np.arange(self.n_words + 1, dtype=np.int32)
+                self.word_csr_t = upload_csr(*transpose_csr(w_rp, h["words"].astype(np.int32), self.vocab_size), dev)
+                self.key_m_pieces, self.key_m = _key_lists(h["wid_m"], self.n_words, dev)
+                self.key_r_pieces, self.key_r = _key_lists(h["wid_root"], self.n_words, dev)
+        return self
+
 
 KEY_CHUNK = 32
 
@@ -357,9 +386,24 @@ def _unique_bounded(ids: np.ndarray, bound: int):
     return values, rank[ids]
 
 
-def prepare_tree(holder, device, vocab_size: int) -> TreePrep:
+def _message_csr(mess_graph, mg: np.ndarray, nm: int):
+    """CSR form of a mess_graph table, remembered on the tensor: the deep-tree check and the holder
+    preparation both start from it."""
+    build = lambda: padded_to_csr(mg, nm)  # noqa: E731
+    return cached_prep(mess_graph, ("m_csr", nm), build) if isinstance(mess_graph, torch.Tensor) else build()
+
+
+def _settling_iterations(mess_graph, m_rp: np.ndarray, m_col: np.ndarray):
+    """Uncapped iteration from which every message of a mess_graph table keeps its value, remembered like
+    the CSR form (the deep-tree check and the schedule both need it)."""
+    build = lambda: K.prep_stable_from(m_rp, m_col, 2 ** 30)  # noqa: E731
+    return cached_prep(mess_graph, ("sf_true",), build) if isinstance(mess_graph, torch.Tensor) else build()
+
+
+def prepare_tree(holder, device, vocab_size: int, train: bool = True) -> TreePrep:
     with packed_uploads(device):
-        return _prepare_tree(holder, device, vocab_size)
+        prep = _prepare_tree(holder, device, vocab_size)
+    return prep.ensure_training() if train else prep
 
 
 def _prepare_tree(holder, device, vocab_size: int) -> TreePrep:
@@ -373,12 +417,10 @@ def _prepare_tree(holder, device, vocab_size: int) -> TreePrep:
         raise ValueError("empty tree batch")
     check_range(fn, vocab_size, "fnode")
     check_range(fm, nn_, "fmess")
-    m_rp, m_col = padded_to_csr(mg, nm)
-    mt_rp, mt_col = transpose_csr(m_rp, m_col, nm)
+    m_rp, m_col = _message_csr(mess_graph, mg, nm)
     roots = np.asarray([st for st, _ in scope], dtype=np.int64)
     check_range(roots, nn_, "scope")
     r_rp, r_col = padded_to_csr(ng[roots], nm)
-    rt_rp, rt_col = transpose_csr(r_rp, r_col, nm)
     nb = roots.shape[0]
 
     words, wid_node = _unique_bounded(fn, vocab_size)
@@ -386,22 +428,20 @@ def _prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     wid_m = wid_node[fm]
     wid_root = wid_node[roots]
     w_rp = np.arange(nw + 1, dtype=np.int64)
-    wt_rp, wt_col = transpose_csr(w_rp.astype(np.int32), words.astype(np.int32), vocab_size)
-
-    km_p, km = _key_lists(wid_m, nw, device)
-    kr_p, kr = _key_lists(wid_root, nw, device)
     ar = np.arange(nb + 1, dtype=np.int64)
+    # forward-only form; ensure_training() adds the transposes and the per-word groupings
     return TreePrep(
         n_nodes=nn_, n_mess=nm, n_trees=nb, n_words=nw,
         words=_dev_i32(words, device),
-        word_csr=upload_csr(w_rp, words, device), word_csr_t=upload_csr(wt_rp, wt_col, device),
+        word_csr=upload_csr(w_rp, words, device), word_csr_t=None,
         wid_m=_dev_i32(wid_m, device), wid_root=_dev_i32(wid_root, device),
-        mcsr=upload_csr(m_rp, m_col, device), mcsr_t=upload_csr(mt_rp, mt_col, device),
-        rcsr=upload_csr(r_rp, r_col, device), rcsr_t=upload_csr(rt_rp, rt_col, device),
+        mcsr=upload_csr(m_rp, m_col, device), mcsr_t=None,
+        rcsr=upload_csr(r_rp, r_col, device), rcsr_t=None,
         ident=upload_csr(ar, ar[:-1], device),
-        key_m_pieces=km_p, key_m=km, key_r_pieces=kr_p, key_r=kr,
+        key_m_pieces=None, key_m=None, key_r_pieces=None, key_r=None,
         vocab_size=vocab_size,
-        host=dict(m_rp=m_rp, m_col=m_col, mt_rp=mt_rp, mt_col=mt_col, wid_m=wid_m, r_col=r_col, device=device),
+        host=dict(m_rp=m_rp, m_col=m_col, mt_rp=None, mt_col=None, wid_m=wid_m, wid_root=wid_root, words=words,
+                  r_rp=r_rp, r_col=r_col, device=device, sf_true=_settling_iterations(mess_graph, m_rp, m_col)),
         schedules={},
     )
 
@@ -463,15 +503,16 @@ def split_deep_trees(holder, T: int):
     the reference's layout over disjoint sets of trees, with the positions of their trees and messages in the
     original batch - so that one deep tree does not drag a whole batch onto the slow, memory-hungry schedule."""
     fnode, fmess, node_graph, mess_graph, scope = holder
-    fn, fm = _to_np(fnode).astype(np.int64), _to_np(fmess).astype(np.int64)
-    ng, mg = _to_np(node_graph).astype(np.int64), _to_np(mess_graph).astype(np.int64)
-    nm = fm.shape[0]
+    mg = np.asarray(_to_np(mess_graph), dtype=np.int64)
+    nm = mg.shape[0]
     if nm <= 1 or T < 1:
         return None
-    m_rp, m_col = padded_to_csr(mg, nm)
-    sf = K.prep_stable_from(m_rp, m_col, 2 ** 30)
+    m_rp, m_col = _message_csr(mess_graph, mg, nm)
+    sf = _settling_iterations(mess_graph, m_rp, m_col)
     if int(sf.max()) <= T:
         return None
+    fn, fm = np.asarray(_to_np(fnode), dtype=np.int64), np.asarray(_to_np(fmess), dtype=np.int64)
+    ng = np.asarray(_to_np(node_graph), dtype=np.int64)
     sc = np.asarray(scope, dtype=np.int64).reshape(-1, 2)
     tree_of_node = np.repeat(np.arange(sc.shape[0], dtype=np.int64), sc[:, 1])
     if tree_of_node.shape[0] != fn.shape[0] or not np.array_equal(sc[:, 0], np.concatenate([[0], np.cumsum(sc[:, 1])[:-1]])):
@@ -508,7 +549,7 @@ def tree_schedule(prep: TreePrep, T: int, dense: bool = False, mode: str = None)
     if key not in prep.schedules:
         h = prep.host
         prep.schedules[key] = build_tree_schedule(h["m_rp"], h["m_col"], h["mt_rp"], h["mt_col"], prep.n_mess, T,
-                                                  h["device"], mode=mode)
+                                                  h["device"], mode=mode, sf_true=h.get("sf_true"))
     return prep.schedules[key]
 
 
@@ -594,7 +635,8 @@ def _levels(rowptr, col, n, cap, start):
     return lev
 
 
-def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False, mode: str = None) -> TreeSchedule:
+def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False, mode: str = None,
+                        sf_true=None) -> TreeSchedule:
     """Row lists of the T GraphGRU iterations.
 
     mode "dense": every message in every iteration, the reference's schedule (jtnn_enc.py:107-128).
@@ -609,7 +651,11 @@ def build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, dense=False, 
     mode = mode or ("dense" if dense else "once")
     if mode not in ("dense", "level", "once"):
         raise ValueError("unknown schedule mode %r" % (mode,))
-    sf_true = K.prep_stable_from(m_rp, m_col, 2 ** 30) if (nm > 0 and mode != "dense") else None  # uncapped
+    if nm > 0 and mode != "dense":
+        if sf_true is None:  # uncapped; a caller that has it already (the deep-tree check) hands it in
+            sf_true = K.prep_stable_from(m_rp, m_col, 2 ** 30)
+    else:
+        sf_true = None
     if mode == "once" and (T < 1 or (nm > 0 and int(sf_true.max()) > T)):
         mode = "level"  # a tree deeper than the iteration count: follow the truncated recurrence
     with packed_uploads(device):
@@ -620,7 +666,8 @@ def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode, sf_tru
     dense = mode == "dense"
     once = mode == "once"
     deg = np.diff(m_rp)
-    tdeg = np.diff(mt_rp)
+    # readers per message: from the transposed lists when they exist, else counted (inference-only holders)
+    tdeg = np.diff(mt_rp) if mt_rp is not None else np.bincount(m_col, minlength=nm)
     if dense or T < 1 or sf_true is None:
         sf = np.full(nm, max(T, 1), dtype=np.int64)
     else:

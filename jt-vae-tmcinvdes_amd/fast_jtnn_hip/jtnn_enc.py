@@ -228,6 +228,8 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         # grad mode is off inside forward(): the caller's mode comes in as an argument
         train = grad_on and any(ctx.needs_input_grad)
         ctx.set_materialize_grads(False)  # an unused output (messages in encode_latent) costs nothing
+        if train:
+            P.ensure_training()
         sched = graphprep.tree_schedule(P, depth, mode=SCHEDULE)
 
         # embedding rows of the words that occur in the batch            (jtnn_enc.py:27-28)
@@ -537,7 +539,8 @@ class JTNNEncoder(nn.Module):
         fnode, fmess, node_graph, mess_graph, scope = holder
         V = self.embedding.weight.shape[0]
         key = mess_graph if isinstance(mess_graph, torch.Tensor) else None
-        build = lambda: graphprep.prepare_tree((fnode, fmess, node_graph, mess_graph, scope), dev, V)  # noqa: E731
+        build = lambda: graphprep.prepare_tree((fnode, fmess, node_graph, mess_graph, scope), dev, V,  # noqa: E731
+                                               torch.is_grad_enabled())
         prep = build() if key is None else graphprep.cached_prep(key, ("tree", str(dev), V), build)
         g = self.GRU
         lin = self.outputNN[0]

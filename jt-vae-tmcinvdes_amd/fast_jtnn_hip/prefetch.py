@@ -30,11 +30,28 @@ def warm_encoder_holders(model, jtenc_holder, mpn_holder, train=True, messages_u
 
     dev = model.mpn.W_h.weight.device
     V = model.jtnn.embedding.weight.shape[0]
-    build = lambda: graphprep.prepare_tree(jtenc_holder, dev, V)  # noqa: E731
-    prep = graphprep.cached_prep(jtenc_holder[3], ("tree", str(dev), V), build)
-    sched = graphprep.tree_schedule(prep, model.jtnn.depth, mode=jtnn_enc.SCHEDULE)
-    if train:
-        graphprep.backward_schedule(prep, sched, all_messages=messages_used)
+
+    def warm_tree(holder):
+        build = lambda: graphprep.prepare_tree(holder, dev, V, train)  # noqa: E731
+        prep = graphprep.cached_prep(holder[3], ("tree", str(dev), V), build)
+        if train:
+            prep.ensure_training()
+        sched = graphprep.tree_schedule(prep, model.jtnn.depth, mode=jtnn_enc.SCHEDULE)
+        if train:
+            graphprep.backward_schedule(prep, sched, all_messages=messages_used)
+        return prep
+
+    prep = None
+    split = None
+    if jtnn_enc.SCHEDULE == "once":
+        # the deep-tree check JTNNEncoder.forward makes first, under the key it looks it up by
+        split = graphprep.cached_prep(jtenc_holder[3], ("deep_split", model.jtnn.depth),
+                                      lambda: graphprep.split_deep_trees(jtenc_holder, model.jtnn.depth))
+    if split is None:
+        prep = warm_tree(jtenc_holder)
+    else:
+        for sub, _, _ in split:
+            warm_tree(sub)
     _holder_prep(*mpn_holder, dev, 0, train)
     return prep
 

@@ -8,11 +8,16 @@ from fast_jtnn_hip import parallel, synthetic, tensorize as T
 from fast_jtnn_hip.prefetch import Prefetcher, warm_encoder_holders
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+mode = sys.argv[3] if len(sys.argv) > 3 else "train"
 dev = torch.device("cuda", 0)
 model, jt, mp, xb, stats = bench.build_problem(1234, B, 385, dev, "train")
 model.overlap_streams = True
 bucket = parallel.FlatGradBucket([p for p in model.parameters() if p.requires_grad])
 def step(jt_, mp_):
+    if mode == "encode":
+        with torch.no_grad():
+            model.encode_vectors(jt_, mp_)
+        return
     bucket.zero()
     mean, logvar = model.encode_latent(jt_, mp_)
     (mean.sum() + logvar.sum()).backward()
@@ -43,18 +48,24 @@ def loop(source, label):
 loop([batches[0]] * 24, "resident, one batch")
 # 2: 12 different batches, all prepared before the loop (twice through, second pass measured)
 ws = [unseen(b) for b in batches]
-for w in ws: warm_encoder_holders(model, w[0], w[1], train=True)
+for w in ws: warm_encoder_holders(model, w[0], w[1], train=mode == "train")
 torch.cuda.synchronize()
 loop(ws * 2, "resident, 12 different batches")
 # 3: prefetched
-for wk, si in ((workers, 5e-3), (2, 5e-3), (6, 5e-3)):
-    sys.setswitchinterval(si)
-    pf = Prefetcher([unseen(b) for b in batches * 2], lambda b: warm_encoder_holders(model, b[0], b[1], train=True), dev, workers=wk)
-    loop(pf, "prefetched, %d workers, switch %g" % (wk, si))
+profile = os.environ.get("PROFILE_STEPPING_THREAD") == "1"
+for wk in ([workers] if profile else [workers, workers + 1, workers + 2, workers + 3]):
+    pf = Prefetcher([unseen(b) for b in batches * 2], lambda b: warm_encoder_holders(model, b[0], b[1], train=mode == "train"), dev, workers=wk, depth=max(4, wk + 1))
+    if profile:
+        import cProfile, pstats
+        pr = cProfile.Profile(); pr.enable()
+    loop(pf, "prefetched, %d workers" % wk)
     pf.close()
+    if profile:
+        pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(14)
 # 4: prep alone, one thread
 t0 = time.perf_counter()
 for b in batches:
-    w = unseen(b); warm_encoder_holders(model, w[0], w[1], train=True)
+    w = unseen(b); warm_encoder_holders(model, w[0], w[1], train=mode == "train")
 torch.cuda.synchronize()
 print("prep alone: %.2f ms/batch" % (1e3 * (time.perf_counter() - t0) / len(batches)))

@@ -182,6 +182,30 @@ def test_copy_rows(K):
     assert np.array_equal(P[:, :39].cpu().numpy(), W[:, :39]) and float(P[:, 39].abs().max()) == 0.0
 
 
+def test_byte_feature_rows_widen_to_the_floats_they_came_from(K):
+    """One-hot feature rows shipped as bytes: the padded device rows carry the bits of the float upload; rows
+    that are not whole numbers in [0, 255] take the float route."""
+    from fast_jtnn_hip import graphprep as G
+
+    rs = np.random.RandomState(3)
+    x = (rs.rand(1237, 39) < 0.1).astype(np.float32)
+    x[5, 7] = 255.0
+    got = G._upload_features(x, "cuda")
+    torch.cuda.synchronize()
+    assert got.shape == (1237, 40) and np.array_equal(got[:, :39].cpu().numpy(), x)
+    assert float(got[:, 39].abs().max()) == 0.0
+    stage = np.empty(x.shape, dtype=np.uint8)
+    assert K.prep_features_to_u8(x, stage) and np.array_equal(stage, x.astype(np.uint8))
+    y = x.copy()
+    y[1000, 38] = 0.5
+    assert not K.prep_features_to_u8(y, stage)
+    got = G._upload_features(y, "cuda")
+    assert np.array_equal(got[:, :39].cpu().numpy(), y) and float(got[:, 39].abs().max()) == 0.0
+    assert K.lib.jtvae_widen_u8_rows(None, got.data_ptr(), 40, 5, 39, None) == K.E_NULL
+    assert K.lib.jtvae_widen_u8_rows(got.data_ptr(), got.data_ptr(), 36, 5, 39, None) == K.E_SHAPE
+    assert K.lib.jtvae_widen_u8_rows(None, None, 40, 0, 39, None) == 0
+
+
 def test_pack_batch(K):
     """Several weight blocks copied / transposed into padded row buffers by one launch."""
     rs = np.random.RandomState(2)

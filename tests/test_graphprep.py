@@ -86,6 +86,33 @@ def test_native_prep_matches_numpy_statements():
         G.padded_to_csr(np.array([[-1, 0]], dtype=np.int64), 9)
 
 
+def test_feature_rows_become_bytes_only_when_that_loses_nothing():
+    from fast_jtnn_hip import _capi as K
+
+    rs = np.random.RandomState(0)
+    x = (rs.rand(9001, 50) < 0.08).astype(np.float32)
+    x[17, 3], x[9000, 49] = 255.0, 6.0
+    out = np.empty(x.shape, dtype=np.uint8)
+    assert K.prep_features_to_u8(x, out) and np.array_equal(out.astype(np.float32), x)
+    for bad in (0.5, -1.0, 256.0, np.nan, np.inf, -0.0, 1e-45):
+        for pos in ((0, 0), (4500, 25), (9000, 49)):  # first block, a middle one, the very last value
+            y = x.copy()
+            y[pos] = bad
+            assert not K.prep_features_to_u8(y, out), (bad, pos)
+    assert K.prep_features_to_u8(np.zeros((0, 39), dtype=np.float32), np.empty((0, 39), dtype=np.uint8))
+    # large enough that the pass is cut into ranges converted side by side: each range reports its own misfit
+    big = (rs.rand(130001, 50) < 0.08).astype(np.float32)
+    out = np.zeros(big.shape, dtype=np.uint8)
+    assert K.prep_features_to_u8(big, out) and np.array_equal(out.astype(np.float32), big)
+    for pos in ((0, 1), (40000, 2), (70000, 3), (100000, 4), (130000, 49)):
+        y = big.copy()
+        y[pos] = 0.25
+        assert not K.prep_features_to_u8(y, out), pos
+    import ctypes
+    assert K.lib.jtvae_prep_features_to_u8(None, 4, None, ctypes.byref(ctypes.c_int32())) == K.E_NULL
+    assert K.lib.jtvae_prep_features_to_u8(None, -1, None, ctypes.byref(ctypes.c_int32())) == K.E_SHAPE
+
+
 def test_compute_once_schedule_covers_every_message_exactly_once():
     """Mode "once": apart from iteration 0 (which evaluates every message on empty inputs), a message is
     updated in exactly one iteration, the one in which it settles, and reads only settled messages."""
