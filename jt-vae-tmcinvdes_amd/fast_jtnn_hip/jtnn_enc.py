@@ -215,11 +215,37 @@ def _keyed_sum(src, pieces, key_csr, n_keys, H, ld, dev):
     return out
 
 
+def _run_groups(groups, side_streams, dev):
+    """Runs independent groups of launches: the last ones on the current stream, the others on the side streams
+    (as far as there are any) behind everything the current stream holds so far; the current stream then waits
+    for them."""
+    cur = torch.cuda.current_stream(dev)
+    n_side = min(len(side_streams), len(groups) - 1)
+    if n_side == 0:
+        for g in groups:
+            g()
+        return
+    start = torch.cuda.Event()
+    start.record(cur)
+    done = []
+    for g, s in zip(groups[:n_side], side_streams):
+        s.wait_event(start)
+        with torch.cuda.stream(s):
+            g()
+            ev = torch.cuda.Event()
+            ev.record(s)
+        done.append(ev)
+    for g in groups[n_side:]:
+        g()
+    for ev in done:
+        cur.wait_event(ev)
+
+
 class _JTNNEncoderFunction(torch.autograd.Function):
     """forward(E, Wout, bout, Wz, bz, Wr, Ur, bu, Wh, bh) -> (tree_vecs [B,H], messages [NM,H])"""
 
     @staticmethod
-    def forward(ctx, E, Wout, bout, Wz, bz, Wr, Ur_w, bu, Wh, bh, prep, depth, grad_on=True):
+    def forward(ctx, E, Wout, bout, Wz, bz, Wr, Ur_w, bu, Wh, bh, prep, depth, grad_on=True, side_streams=()):
         dev = E.device
         H = Wr.shape[0]
         ld = K.round_ld(H)
@@ -261,6 +287,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
             ctx.st, ctx.sched = st, sched
             ctx.keep = (Eu, Pr, nsum, tv, Wout, Wz, Wr, Ur_w, Wh)
             ctx.vocab = E.shape[0]
+            ctx.side_streams = tuple(side_streams)
         return dense_view(tv, H), dense_view(h, H)
 
     @staticmethod
@@ -306,36 +333,52 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         if T >= 1:
             dz, dp, du, a_r = _TreeGRU.backward(dh, sched, bs, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT,
                                                 WhhT, UrT)
-        # weight gradients of the three per-iteration GEMMs: one contraction each over every
-        # (iteration, message) pair that carried gradient, operands picked through row lists
-        if T >= 1 and bs.n_z > 0:
-            K.gemm_tn(dz.data_ptr(), ld, st["ss"].data_ptr(), ld, K.ptr(dWz, H), 2 * H, bs.n_z, H, H, False, dev,
-                      x_rows=bs.zx.data_ptr(), y_rows=bs.zy.data_ptr())
-            K.gemm_tn(dp.data_ptr(), ld, st["gs"].data_ptr(), ld, K.ptr(dWh, H), 2 * H, bs.n_z, H, H, False, dev,
-                      x_rows=bs.zx.data_ptr(), y_rows=bs.zy.data_ptr())
-        else:
-            dWz[:, H:].zero_()
-            dWh[:, H:].zero_()
-        if T >= 1 and bs.n_u > 0:
-            # the row pairs visit every compact du row exactly once, so the fused column sum is U_r's bias gradient
-            K.gemm_tn(du.data_ptr(), ld, st["hs"].data_ptr(), ld, dUr.data_ptr(), H, bs.n_u, H, H, False, dev,
-                      x_rows=bs.ux.data_ptr(), y_rows=bs.uy.data_ptr(), dbias=dbu.data_ptr())
-        else:
-            dUr.zero_()
-            dbu.zero_()
+        # What follows the sweep is a run of short launches (three weight-gradient contractions, and per table
+        # two keyed sums and one more contraction) that leave most of the GPU idle when issued one after another.
+        # The groups below do not depend on each other; given side streams they run side by side and are joined
+        # before the embedding gradient.  Each group is the same launches on the same data either way.
+        def gru_weight_grads():
+            # one contraction each over every (iteration, message) pair that carried gradient, operands picked
+            # through row lists
+            if T >= 1 and bs.n_z > 0:
+                K.gemm_tn(dz.data_ptr(), ld, st["ss"].data_ptr(), ld, K.ptr(dWz, H), 2 * H, bs.n_z, H, H, False, dev,
+                          x_rows=bs.zx.data_ptr(), y_rows=bs.zy.data_ptr())
+                K.gemm_tn(dp.data_ptr(), ld, st["gs"].data_ptr(), ld, K.ptr(dWh, H), 2 * H, bs.n_z, H, H, False, dev,
+                          x_rows=bs.zx.data_ptr(), y_rows=bs.zy.data_ptr())
+            else:
+                dWz[:, H:].zero_()
+                dWh[:, H:].zero_()
+            if T >= 1 and bs.n_u > 0:
+                # the row pairs visit every compact du row exactly once, so the fused column sum is U_r's bias
+                # gradient
+                K.gemm_tn(du.data_ptr(), ld, st["hs"].data_ptr(), ld, dUr.data_ptr(), H, bs.n_u, H, H, False, dev,
+                          x_rows=bs.ux.data_ptr(), y_rows=bs.uy.data_ptr(), dbias=dbu.data_ptr())
+            else:
+                dUr.zero_()
+                dbu.zero_()
 
-        # gradients of the per-word tables
-        dPo = _keyed_sum(dpre_root, P.key_r_pieces, P.key_r, NW, H, ld, dev)
-        if T >= 1 and bs.nE > 0:
-            dPz = _keyed_sum(dz, bs.key_pieces, bs.key, NW, H, ld, dev)
-            dPh = _keyed_sum(dp, bs.key_pieces, bs.key, NW, H, ld, dev)
-            dPr = _keyed_sum(a_r, P.key_m_pieces, P.key_m, NW, H, ld, dev)
-        else:
-            dPz, dPh, dPr = (K.rows(NW, ld, dev, zero=True) for _ in range(3))
-        for dPt, dW, db in ((dPz, dWz, dbz), (dPh, dWh, dbh), (dPo, dWout, dbout)):
-            K.gemm_tn(dPt.data_ptr(), ld, Eu.data_ptr(), ld, dW.data_ptr(), 2 * H, NW, H, H, False, dev,
-                      dbias=db.data_ptr())
-        K.gemm_tn(dPr.data_ptr(), ld, Eu.data_ptr(), ld, dWr.data_ptr(), H, NW, H, H, False, dev)
+        swept = T >= 1 and bs.nE > 0
+        tables = {}
+        home = torch.cuda.current_stream(dev)
+
+        def table_grad(name, src, pieces, key_csr, dW, lddw, db):
+            # gradient of one per-word table, and of the weight block (and bias) that produced it
+            dPt = _keyed_sum(src, pieces, key_csr, NW, H, ld, dev) if src is not None else K.rows(NW, ld, dev, zero=True)
+            K.gemm_tn(dPt.data_ptr(), ld, Eu.data_ptr(), ld, dW.data_ptr(), lddw, NW, H, H, False, dev,
+                      dbias=None if db is None else db.data_ptr())
+            if torch.cuda.current_stream(dev) != home:
+                dPt.record_stream(home)  # made on a side stream, read on this pass's own stream below
+            tables[name] = dPt
+
+        groups = [
+            gru_weight_grads,
+            lambda: (table_grad("z", dz if swept else None, bs.key_pieces, bs.key, dWz, 2 * H, dbz),
+                     table_grad("h", dp if swept else None, bs.key_pieces, bs.key, dWh, 2 * H, dbh)),
+            lambda: (table_grad("o", dpre_root, P.key_r_pieces, P.key_r, dWout, 2 * H, dbout),
+                     table_grad("r", a_r if swept else None, P.key_m_pieces, P.key_m, dWr, H, None)),
+        ]
+        _run_groups(groups, ctx.side_streams, dev)
+        dPz, dPh, dPo, dPr = (tables[k] for k in "zhor")
         # embedding gradient: dEu = sum_tables dP W[:, :H], scattered to the rows of the words used
         dEu = K.rows(NW, ld, dev)
         first = True
@@ -348,7 +391,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
                          P.word_csr_t.col.data_ptr(), V, H, ld, nnz=NW)
         dE = torch.empty((V, H), dtype=torch.float32, device=dev)
         K.copy_rows(dE_p.data_ptr(), ld, dE.data_ptr(), H, V, H)
-        return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None, None
+        return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None, None, None
 
 
 class _MessageGRUFunction(torch.autograd.Function):
@@ -510,6 +553,10 @@ class JTNNEncoder(nn.Module):
         self.outputNN = nn.Sequential(nn.Linear(2 * hidden_size, hidden_size), nn.ReLU())
         self.GRU = GraphGRU(hidden_size, hidden_size, depth=depth)
 
+    # Streams the backward pass may use beside its own for the independent groups of short launches that follow
+    # its level sweep (set by a caller that overlaps the two encoders; empty: everything on one stream).
+    side_streams = ()
+
     def forward(self, fnode, fmess, node_graph, mess_graph, scope):
         dev = self.GRU.W_r.weight.device
         if dev.type != "cuda":
@@ -547,7 +594,8 @@ class JTNNEncoder(nn.Module):
         with torch.cuda.device(dev):
             return _JTNNEncoderFunction.apply(self.embedding.weight, lin.weight, lin.bias, g.W_z.weight,
                                               g.W_z.bias, g.W_r.weight, g.U_r.weight, g.U_r.bias,
-                                              g.W_h.weight, g.W_h.bias, prep, self.depth, torch.is_grad_enabled())
+                                              g.W_h.weight, g.W_h.bias, prep, self.depth, torch.is_grad_enabled(),
+                                              self.side_streams)
 
     @staticmethod
     def tensorize(tree_batch):

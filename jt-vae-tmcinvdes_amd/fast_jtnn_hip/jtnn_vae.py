@@ -126,16 +126,20 @@ class JTNNVAE(nn.Module):
         cache = self.__dict__.setdefault("_stream_cache", {})
         key = (device.type, device.index)
         if key not in cache:
-            cache[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            cache[key] = tuple(torch.cuda.Stream(device=device) for _ in range(3))
         return cache[key]
 
     def encode(self, jtenc_holder, mpn_holder):  # jtnn_vae.py:45-48
         device = self.mpn.W_h.weight.device
         if not (self.overlap_streams and device.type == "cuda"):
+            self.jtnn.side_streams = ()
             tree_vecs, tree_mess = self.jtnn(*jtenc_holder)
             mol_vecs = self.mpn(*mpn_holder)
             return tree_vecs, tree_mess, mol_vecs
-        s_tree, s_graph = self._side_streams(device)
+        s_tree, s_graph, s_aux = self._side_streams(device)
+        # the tree encoder's backward pass ends in groups of short launches that can run side by side (a second
+        # and third helper stream were measured and add nothing to the first)
+        self.jtnn.side_streams = (s_aux,)
         cur = torch.cuda.current_stream(device)
         s_tree.wait_stream(cur)
         s_graph.wait_stream(cur)

@@ -111,6 +111,38 @@ def test_training_step_matches_oracle_on_fresh_batches(seed, B, atoms):
         assert f < (1e-3 if name.startswith("jtmpn.") else 2e-4), (name, f)
 
 
+@pytest.mark.parametrize("B,atoms", [(256, 40.0), (5, 12.0)])
+def test_two_stream_step_is_bitwise_the_one_stream_step(B, atoms):
+    """The encoders on two overlapping streams (the tree encoder's backward pass spreading its closing groups
+    of launches over a helper stream) against everything on one stream: the same launches on the same data, so
+    every output and every gradient carries the same bits - checked over several steps, so that a buffer handed
+    back to the allocator while another stream still reads it would show."""
+    g, x_batch = _seeded_training_problem(77, B, atoms)
+    hip = make_hip_model(g, "cuda")
+    _, jt, mp, _ = x_batch()
+
+    def step(overlap):
+        hip.overlap_streams = overlap
+        for p in hip.parameters():
+            p.grad = None
+        mean, logvar = hip.encode_latent(jt, mp)
+        w = torch.linspace(0.5, 1.5, mean.shape[1], device="cuda")
+        ((mean * w).sum() + (logvar * w.flip(0)).sum()).backward()
+        torch.cuda.synchronize()
+        return ([mean.detach().clone(), logvar.detach().clone()] +
+                [p.grad.clone() for n, p in hip.named_parameters() if p.grad is not None])
+
+    ref = step(False)
+    assert len(ref) > 12
+    for it in range(4):
+        got = step(True)
+        assert len(got) == len(ref)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), it
+    again = step(False)
+    assert all(torch.equal(a, b) for a, b in zip(again, ref))
+
+
 def test_decoder_alone_matches_oracle_and_leaves_the_batch_untouched():
     g, x_batch = _seeded_training_problem(41, 16, 24.0, V=60)
     hip, ora = make_hip_model(g, "cuda"), make_oracle_vae(g)
