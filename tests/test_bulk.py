@@ -110,6 +110,60 @@ def test_prefetched_holders_give_bitwise_the_same_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("train", [True, False])
+def test_prefetching_a_batch_with_a_deep_tree_prepares_both_of_its_parts(train):
+    """A chain of 30 clusters among ordinary trees is split off the batch (it is deeper than the 20 iterations).
+    The background thread prepares the split and both parts under the keys the encoder looks them up by, so the
+    stepping thread finds everything ready - holders prepared for inference carry no backward tables - and the
+    results are those of the direct call, bit for bit."""
+    from fast_jtnn_hip import JTNNVAE, graphprep, synthetic, tensorize as T
+    from fast_jtnn_hip.prefetch import Prefetcher, warm_encoder_holders
+
+    V = 40
+    model = JTNNVAE(synthetic.FakeVocab(V), 450, 56, 20, 3)
+    synthetic.fill_params(list(model.named_parameters()), seed=5, bias_scale=0.05)
+    model = model.cuda()
+
+    def batches():
+        for i in range(3):
+            trees = synthetic.make_batch(60 + i, 32, vocab_size=V, mean_atoms=20.0)
+            chain = [synthetic.TreeNode(k + 1, (7 * k + i) % V) for k in range(30)]
+            for a, b in zip(chain[:-1], chain[1:]):
+                a.neighbors.append(b); b.neighbors.append(a)
+            trees.insert(11, synthetic.Tree(chain, trees[0].mol))
+            synthetic.set_batch_nodeID(trees)
+            yield T.jtenc_tensorize(trees)[0], T.mpn_tensorize([t.mol for t in trees])
+
+    def run(source, check_ready=False):
+        out = []
+        for jt, mp in source:
+            if check_ready:
+                cache = getattr(jt[3], graphprep._CACHE_ATTR)
+                split = cache[("deep_split", 20)]
+                assert split is not None and len(split) == 2
+                for sub, _, _ in split:
+                    prep = getattr(sub[3], graphprep._CACHE_ATTR)[("tree", "cuda:0", V)]
+                    assert (prep.mcsr_t is not None) == train and len(prep.schedules) == 1
+            if train:
+                model.zero_grad()
+                mean, logvar = model.encode_latent(jt, mp)
+                (mean.sum() - logvar.sum()).backward()
+                out.append([mean.detach().clone(), logvar.detach().clone()] +
+                           [p.grad.clone() for p in model.parameters() if p.grad is not None])
+            else:
+                with torch.no_grad():
+                    out.append([model.encode_vectors(jt, mp).clone()])
+        return out
+
+    direct = run(batches())
+    with Prefetcher(batches(), lambda b: warm_encoder_holders(model, b[0], b[1], train=train), "cuda:0", depth=2) as pf:
+        ahead = run(pf, check_ready=True)
+    assert len(direct) == len(ahead) == 3
+    for a, b in zip(direct, ahead):
+        assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
 def test_bulk_encoding_at_job_scale_matches_oracle_on_a_sample(tmp_path):
     """The latent-generation job's shape: batches of 4096 graphs, vocabulary of 1251 entries, streamed through
     encode_bulk with prefetch; a 64-molecule sub-sample of the written rows against the CPU oracle (1e-4), the
