@@ -142,6 +142,32 @@ def test_two_stream_step_is_bitwise_the_one_stream_step(B, atoms):
     again = step(False)
     assert all(torch.equal(a, b) for a, b in zip(again, ref))
 
+    # the same with the candidate-graph encoder reading the tree messages, so that their gradient enters the
+    # tree encoder's backward pass from outside (encoders, both KL terms and the assembly loss; no decoder, whose
+    # torch-side index adds are not reproducible run to run)
+    xb = x_batch()
+    trees, jt, mp, assm_holder = xb
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    eps = [torch.randn((B, 28), generator=gen).cuda() for _ in range(2)]
+
+    def assm_step(overlap):
+        hip.overlap_streams = overlap
+        for p in hip.parameters():
+            p.grad = None
+        tree_vecs, tree_mess, mol_vecs = hip.encode(jt, mp)
+        _, tree_kl = hip.rsample(tree_vecs, hip.T_mean, hip.T_var, eps[0])
+        z_mol, mol_kl = hip.rsample(mol_vecs, hip.G_mean, hip.G_var, eps[1])
+        assm_loss, _ = hip.assm(trees, assm_holder, z_mol, tree_mess)
+        loss = assm_loss + 0.01 * (tree_kl + mol_kl)
+        loss.backward()
+        torch.cuda.synchronize()
+        return [loss.detach().clone()] + [p.grad.clone() for p in hip.parameters() if p.grad is not None]
+
+    ref = assm_step(False)
+    for it in range(3):
+        got = assm_step(True)
+        assert len(got) == len(ref) and all(torch.equal(a, b) for a, b in zip(got, ref)), it
+
 
 def test_decoder_alone_matches_oracle_and_leaves_the_batch_untouched():
     g, x_batch = _seeded_training_problem(41, 16, 24.0, V=60)
