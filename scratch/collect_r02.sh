@@ -5,7 +5,7 @@
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 if [ "$1" = profile ]; then
-for w in "train 1024" "encode 1024" "encode 4096" "train_assm 1024" "train_full 512" "train_full 4096" "train_prop 512"; do
+for w in "train 1024" "train 4096" "encode 1024" "encode 4096" "train_assm 1024" "train_full 512" "train_full 4096" "train_prop 512"; do
   set -- $w
   bash $R/scratch/profile_r02.sh $1 $2 all || exit 1
 done
