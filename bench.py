@@ -128,6 +128,39 @@ def cpu_model_name():
     return "unknown CPU"
 
 
+ROW_CLASSES = ((40000, ">= 40000 rows"), (2000, "2000 .. 39999 rows"), (0, "< 2000 rows"))
+NARROW = "feature-row products (inner or output extent < 128: bound by the rows they move, not by MFMA)"
+
+
+def rows_breakdown(detail, steps):
+    """MFMA kernels by the row count of the launch (from the shape tag the kernel timer files a call under):
+    per class the launches per step, their time and the rate they reach."""
+    import re
+
+    out = {}
+    for (name, tag), d in detail.items():
+        if name not in MFMA_KERNELS:
+            continue
+        m = re.search(r"M=(\d+)(?:\+(\d+))?", tag)
+        if not m:
+            continue
+        rows = max(int(g) for g in m.groups() if g)
+        label = next(lab for lo, lab in ROW_CLASSES if rows >= lo)
+        nk = re.search(r"N=(\d+) K=(\d+)", tag)
+        if nk and min(int(nk.group(1)), int(nk.group(2))) < 128:
+            label = NARROW
+        c = out.setdefault(name, {}).setdefault(label, dict(launches=0, ms=0.0, flops=0))
+        c["launches"] += d["launches"]
+        c["ms"] += d["ms"]
+        c["flops"] += d["flops"]
+    res = {}
+    for name, classes in out.items():
+        res[name] = [dict(rows=label, launches=c["launches"] // steps, ms_per_step=round(c["ms"] / steps, 4),
+                          achieved=round(c["flops"] / max(c["ms"], 1e-9) / 1e9, 2), unit="TFLOP/s")
+                     for label in [lab for _, lab in ROW_CLASSES] + [NARROW] for c in [classes.get(label)] if c]
+    return res
+
+
 def cpu_baseline(seed, vocab, sample_b=256, reps=2, grad=True, keep=None):
     """The CPU oracle (the reference's op sequence in PyTorch CPU ops) on a bounded sample of the
     same workload, timed on this host's cores.  ``keep`` (a dict) receives the sample's holders and the
@@ -407,6 +440,7 @@ def main():
                                                               d["ms"] / KT_STEPS, tf), file=sys.stderr)
         kernels = []
         summary = kt.summary()
+        by_rows = rows_breakdown(kt.detail(), KT_STEPS)
         for d in summary.values():  # per step: every step issues the same launches
             assert d["launches"] % KT_STEPS == 0, summary
             d["launches"] //= KT_STEPS
@@ -428,6 +462,8 @@ def main():
                 row.update(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                            frac=round(ach / HBM_PEAK_GBS, 4), frac_of_copy_peak=round(ach / HBM_COPY_PEAK_GBS, 4))
             row["algorithmic_bytes_per_launch"] = round(d["bytes"] / d["launches"])
+            if name in by_rows:
+                row["by_rows"] = by_rows[name]  # the average above is over launches of very different sizes
             row["traffic"] = round(traffic[name]) if name in traffic else None
             kernels.append(row)
         kernels.sort(key=lambda k: -k["ms_per_step"])
