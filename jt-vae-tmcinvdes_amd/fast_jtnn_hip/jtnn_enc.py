@@ -218,27 +218,26 @@ def _keyed_sum(src, pieces, key_csr, n_keys, H, ld, dev):
 def _run_groups(groups, side_streams, dev):
     """Runs independent groups of launches: the last ones on the current stream, the others on the side streams
     (as far as there are any) behind everything the current stream holds so far; the current stream then waits
-    for them."""
+    for them.  Returns what the groups returned."""
     cur = torch.cuda.current_stream(dev)
     n_side = min(len(side_streams), len(groups) - 1)
     if n_side == 0:
-        for g in groups:
-            g()
-        return
+        return [g() for g in groups]
     start = torch.cuda.Event()
     start.record(cur)
-    done = []
+    done, out = [], []
     for g, s in zip(groups[:n_side], side_streams):
         s.wait_event(start)
         with torch.cuda.stream(s):
-            g()
+            out.append(g())
             ev = torch.cuda.Event()
             ev.record(s)
         done.append(ev)
     for g in groups[n_side:]:
-        g()
+        out.append(g())
     for ev in done:
         cur.wait_event(ev)
+    return out
 
 
 class _JTNNEncoderFunction(torch.autograd.Function):
@@ -270,10 +269,16 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         K.gemm_nt(Eu.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NW, H, H, bias=bz.detach().data_ptr())
         K.gemm_nt(Eu.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NW, H, H)
         K.gemm_nt(Eu.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NW, H, H, bias=bh.detach().data_ptr())
-        K.gemm_nt(Eu.data_ptr(), ld, Wox.data_ptr(), ld, Po.data_ptr(), ld, NW, H, H, bias=bout.detach().data_ptr())
 
-        h, st = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p, bu.detach(), Whh,
-                                 train)
+        def root_table():  # read by the output stage only: off the chain of the sweep when there is a side stream
+            K.gemm_nt(Eu.data_ptr(), ld, Wox.data_ptr(), ld, Po.data_ptr(), ld, NW, H, H,
+                      bias=bout.detach().data_ptr())
+
+        def sweep():
+            return _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p, bu.detach(), Whh,
+                                    train)
+
+        (h, st), = _run_groups([root_table, sweep], side_streams, dev)[1:]
 
         # output stage on the root nodes only                             (jtnn_enc.py:31-41)
         nsum = K.rows(B, ld, dev)
@@ -320,7 +325,6 @@ class _JTNNEncoderFunction(torch.autograd.Function):
             dtv_p = as_row_buffer(dtv, H, ld)
             K.csr_gather_sum(dpre_root.data_ptr(), dtv_p.data_ptr(), B, None, P.ident.rowptr.data_ptr(),
                              P.ident.col.data_ptr(), B, H, ld, relu_mask=tv.data_ptr(), nnz=B)
-        K.gemm_tn(dpre_root.data_ptr(), ld, nsum.data_ptr(), ld, K.ptr(dWout, H), 2 * H, B, H, H, False, dev)
         dnsum = K.rows(B, ld, dev)
         K.gemm_nt(dpre_root.data_ptr(), ld, WohT.data_ptr(), ld, dnsum.data_ptr(), ld, B, H, H)
         dh = K.rows(NM, ld, dev)
@@ -338,6 +342,8 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         # The groups below do not depend on each other; given side streams they run side by side and are joined
         # before the embedding gradient.  Each group is the same launches on the same data either way.
         def gru_weight_grads():
+            # W_out[:, H:] from the root stage (nothing in the sweep waits for it)
+            K.gemm_tn(dpre_root.data_ptr(), ld, nsum.data_ptr(), ld, K.ptr(dWout, H), 2 * H, B, H, H, False, dev)
             # one contraction each over every (iteration, message) pair that carried gradient, operands picked
             # through row lists
             if T >= 1 and bs.n_z > 0:
