@@ -215,29 +215,26 @@ def _keyed_sum(src, pieces, key_csr, n_keys, H, ld, dev):
     return out
 
 
-def _run_groups(groups, side_streams, dev):
-    """Runs independent groups of launches: the last ones on the current stream, the others on the side streams
-    (as far as there are any) behind everything the current stream holds so far; the current stream then waits
-    for them.  Returns what the groups returned."""
-    cur = torch.cuda.current_stream(dev)
-    n_side = min(len(side_streams), len(groups) - 1)
-    if n_side == 0:
-        return [g() for g in groups]
+def _aside(fn, side_streams, dev, which=0):
+    """fn() on side stream ``which`` behind everything the current stream holds so far; returns the event to wait
+    for before its results are read (None: there is no such stream and fn ran in place)."""
+    if len(side_streams) <= which:
+        fn()
+        return None
+    s = side_streams[which]
     start = torch.cuda.Event()
-    start.record(cur)
-    done, out = [], []
-    for g, s in zip(groups[:n_side], side_streams):
-        s.wait_event(start)
-        with torch.cuda.stream(s):
-            out.append(g())
-            ev = torch.cuda.Event()
-            ev.record(s)
-        done.append(ev)
-    for g in groups[n_side:]:
-        out.append(g())
-    for ev in done:
-        cur.wait_event(ev)
-    return out
+    start.record(torch.cuda.current_stream(dev))
+    s.wait_event(start)
+    with torch.cuda.stream(s):
+        fn()
+        ev = torch.cuda.Event()
+        ev.record(s)
+    return ev
+
+
+def _join(ev, dev):
+    if ev is not None:
+        torch.cuda.current_stream(dev).wait_event(ev)
 
 
 class _JTNNEncoderFunction(torch.autograd.Function):
@@ -266,19 +263,18 @@ class _JTNNEncoderFunction(torch.autograd.Function):
             [(Wz, 0, H, False), (Wz, H, H, False), (Wh, 0, H, False), (Wh, H, H, False), (Wout, 0, H, False),
              (Wout, H, H, False), (Wr, 0, H, False), (Ur_w, 0, H, False)])
         Pz, Pr, Ph, Po = (K.rows(NW, ld, dev) for _ in range(4))
+        # the reset-gate table is first read by level 1 of the sweep and the output table after it: with a side
+        # stream they leave the chain of dependent launches that the sweep is
+        ev_r = _aside(lambda: K.gemm_nt(Eu.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NW, H, H),
+                      side_streams, dev)
+        ev_o = _aside(lambda: K.gemm_nt(Eu.data_ptr(), ld, Wox.data_ptr(), ld, Po.data_ptr(), ld, NW, H, H,
+                                        bias=bout.detach().data_ptr()), side_streams, dev)
         K.gemm_nt(Eu.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NW, H, H, bias=bz.detach().data_ptr())
-        K.gemm_nt(Eu.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NW, H, H)
         K.gemm_nt(Eu.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NW, H, H, bias=bh.detach().data_ptr())
-
-        def root_table():  # read by the output stage only: off the chain of the sweep when there is a side stream
-            K.gemm_nt(Eu.data_ptr(), ld, Wox.data_ptr(), ld, Po.data_ptr(), ld, NW, H, H,
-                      bias=bout.detach().data_ptr())
-
-        def sweep():
-            return _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p, bu.detach(), Whh,
-                                    train)
-
-        (h, st), = _run_groups([root_table, sweep], side_streams, dev)[1:]
+        _join(ev_r, dev)
+        h, st = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p, bu.detach(), Whh,
+                                 train)
+        _join(ev_o, dev)
 
         # output stage on the root nodes only                             (jtnn_enc.py:31-41)
         nsum = K.rows(B, ld, dev)
@@ -325,6 +321,27 @@ class _JTNNEncoderFunction(torch.autograd.Function):
             dtv_p = as_row_buffer(dtv, H, ld)
             K.csr_gather_sum(dpre_root.data_ptr(), dtv_p.data_ptr(), B, None, P.ident.rowptr.data_ptr(),
                              P.ident.col.data_ptr(), B, H, ld, relu_mask=tv.data_ptr(), nnz=B)
+        tables = {}
+        home = torch.cuda.current_stream(dev)
+
+        def table_grad(name, src, pieces, key_csr, dW, lddw, db):
+            # gradient of one per-word table, and of the weight block (and bias) that produced it
+            dPt = _keyed_sum(src, pieces, key_csr, NW, H, ld, dev) if src is not None else K.rows(NW, ld, dev, zero=True)
+            K.gemm_tn(dPt.data_ptr(), ld, Eu.data_ptr(), ld, dW.data_ptr(), lddw, NW, H, H, False, dev,
+                      dbias=None if db is None else db.data_ptr())
+            if torch.cuda.current_stream(dev) != home:
+                dPt.record_stream(home)  # made on a side stream, read on this pass's own stream below
+            tables[name] = dPt
+
+        def root_stage_grads():
+            # W_out[:, H:] and everything that hangs on the output table: nothing in the sweep waits for them
+            K.gemm_tn(dpre_root.data_ptr(), ld, nsum.data_ptr(), ld, K.ptr(dWout, H), 2 * H, B, H, H, False, dev)
+            table_grad("o", dpre_root, P.key_r_pieces, P.key_r, dWout, 2 * H, dbout)
+
+        # With a side stream, work that the chain of the sweep does not wait for runs beside it: the root stage's
+        # weight and table gradients now, the recurrence's weight gradients after the sweep.  The same launches
+        # on the same data either way.
+        ev_root = _aside(root_stage_grads, ctx.side_streams, dev)
         dnsum = K.rows(B, ld, dev)
         K.gemm_nt(dpre_root.data_ptr(), ld, WohT.data_ptr(), ld, dnsum.data_ptr(), ld, B, H, H)
         dh = K.rows(NM, ld, dev)
@@ -337,13 +354,8 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         if T >= 1:
             dz, dp, du, a_r = _TreeGRU.backward(dh, sched, bs, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT,
                                                 WhhT, UrT)
-        # What follows the sweep is a run of short launches (three weight-gradient contractions, and per table
-        # two keyed sums and one more contraction) that leave most of the GPU idle when issued one after another.
-        # The groups below do not depend on each other; given side streams they run side by side and are joined
-        # before the embedding gradient.  Each group is the same launches on the same data either way.
+
         def gru_weight_grads():
-            # W_out[:, H:] from the root stage (nothing in the sweep waits for it)
-            K.gemm_tn(dpre_root.data_ptr(), ld, nsum.data_ptr(), ld, K.ptr(dWout, H), 2 * H, B, H, H, False, dev)
             # one contraction each over every (iteration, message) pair that carried gradient, operands picked
             # through row lists
             if T >= 1 and bs.n_z > 0:
@@ -363,27 +375,15 @@ class _JTNNEncoderFunction(torch.autograd.Function):
                 dUr.zero_()
                 dbu.zero_()
 
+        # after the sweep: a run of short launches (three weight-gradient contractions, and per table two keyed
+        # sums and one more contraction) that would leave most of the GPU idle one after another
+        ev_w = _aside(gru_weight_grads, ctx.side_streams, dev)
         swept = T >= 1 and bs.nE > 0
-        tables = {}
-        home = torch.cuda.current_stream(dev)
-
-        def table_grad(name, src, pieces, key_csr, dW, lddw, db):
-            # gradient of one per-word table, and of the weight block (and bias) that produced it
-            dPt = _keyed_sum(src, pieces, key_csr, NW, H, ld, dev) if src is not None else K.rows(NW, ld, dev, zero=True)
-            K.gemm_tn(dPt.data_ptr(), ld, Eu.data_ptr(), ld, dW.data_ptr(), lddw, NW, H, H, False, dev,
-                      dbias=None if db is None else db.data_ptr())
-            if torch.cuda.current_stream(dev) != home:
-                dPt.record_stream(home)  # made on a side stream, read on this pass's own stream below
-            tables[name] = dPt
-
-        groups = [
-            gru_weight_grads,
-            lambda: (table_grad("z", dz if swept else None, bs.key_pieces, bs.key, dWz, 2 * H, dbz),
-                     table_grad("h", dp if swept else None, bs.key_pieces, bs.key, dWh, 2 * H, dbh)),
-            lambda: (table_grad("o", dpre_root, P.key_r_pieces, P.key_r, dWout, 2 * H, dbout),
-                     table_grad("r", a_r if swept else None, P.key_m_pieces, P.key_m, dWr, H, None)),
-        ]
-        _run_groups(groups, ctx.side_streams, dev)
+        table_grad("z", dz if swept else None, bs.key_pieces, bs.key, dWz, 2 * H, dbz)
+        table_grad("h", dp if swept else None, bs.key_pieces, bs.key, dWh, 2 * H, dbh)
+        table_grad("r", a_r if swept else None, P.key_m_pieces, P.key_m, dWr, H, None)
+        _join(ev_root, dev)
+        _join(ev_w, dev)
         dPz, dPh, dPo, dPr = (tables[k] for k in "zhor")
         # embedding gradient: dEu = sum_tables dP W[:, :H], scattered to the rows of the words used
         dEu = K.rows(NW, ld, dev)
