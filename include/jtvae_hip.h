@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 12
+#define JTVAE_ABI_VERSION 13
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -261,6 +261,16 @@ int jtvae_gru_bwd_gather(const float* h, const float* Uh, size_t slab_stride, in
                          const float* dg, const float* ds, const int32_t* trowptr, const int32_t* tcol,
                          const int32_t* rows, int32_t n_rows, const float* dh_ext, float* dUh, float* dhdir,
                          int32_t H, int32_t ld, void* stream);
+
+/* One level of the backward recurrence from the gathered dU_r h rows to the pre-activation gradients, in one
+ * launch where the shapes allow it: dh[rows[i]] = du[i] . UrT^T + dhdir[rows[i]] (the jtvae_gemm_nt that follows
+ * jtvae_gru_bwd_gather), and from that value, in the epilogue, what jtvae_gru_bwd_pointwise computes: dzpre[i],
+ * dppre[i] (compact) and ds[rows[i]].  Same arguments and the same bits as the two calls; rows beyond 10 000 or
+ * unaligned operands run as those two launches.  UrT: [H, ldw] (U_r transposed). */
+int jtvae_gru_bwd_dh(const float* du, const float* UrT, int32_t ldw, const float* dhdir, float* dh,
+                     const int32_t* rows, int32_t n_rows, const float* z, const float* p, const float* s,
+                     size_t slab_stride, int32_t t_iter, const int32_t* sf, float* dzpre, float* dppre, float* ds,
+                     int32_t H, int32_t ld, int32_t pad_row, void* stream);
 
 /* ---- whole level sweeps of the compute-once schedule, one host call each ---------------------- */
 

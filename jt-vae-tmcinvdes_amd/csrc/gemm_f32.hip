@@ -90,7 +90,16 @@ struct NtArgs {
   int n_blocks;
   int evec;  // epilogue operands are float4-addressable
   jtvae_epilogue_t e;
+  // EPI_GRU_BWD only: s rows (by message id, like e.aux0 = z and e.aux1 = p) and the compact outputs
+  const float* bw_s;
+  float* bw_dz;
+  float* bw_dp;
 };
+
+// Internal epilogue mode of jtvae_gru_bwd_dh: the product is the gradient dh of the level's rows, and what the
+// pointwise backward of the blend / sigmoid / tanh makes of it is written in the same pass (dz, dp compactly by
+// launch row; ds by message id into e.out2).
+constexpr int EPI_GRU_BWD = 3;
 
 // Tile loads are split in two so that they stay in flight behind the MFMAs of the current
 // tile: load4_raw issues an unconditional load from a clamped (always valid) address, mask4
@@ -133,6 +142,8 @@ struct EpiRow {
   int m;      // id of the output row
   int add_m;  // row of the add operand
   int tau;    // MUL_ACC: slab of the multiplier row, -1 = no multiplier (nothing to accumulate)
+              // GRU_BWD: slab of the row's saved state (0: the row has no s)
+  int i;      // row of the launch (compact outputs are indexed by it)
 };
 
 template <int MODE>
@@ -142,10 +153,12 @@ __device__ __forceinline__ EpiRow epi_row(const NtArgs& a, int i) {
   R.m = e.c_rows ? e.c_rows[i] : i;
   R.add_m = (e.add && e.add_idx) ? e.add_idx[R.m] : R.m;
   R.tau = 0;
+  R.i = i;
   if (MODE == JTVAE_EPI_MUL_ACC && e.aux_sf) {
     R.tau = min(e.aux_t, e.aux_sf[R.m] - 1);
     if (R.tau <= 0) R.tau = -1;  // slab 0 is all zero
   }
+  if (MODE == EPI_GRU_BWD) R.tau = e.aux_sf ? min(e.aux_t, e.aux_sf[R.m] - 1) : e.aux_t;
   return R;
 }
 __device__ __forceinline__ float* epi_c_row(const NtArgs& a, const EpiRow& R) { return a.C + (size_t)R.m * a.ldc; }
@@ -167,6 +180,11 @@ __device__ __forceinline__ void epi_store(const NtArgs& a, const EpiRow& R, int 
     if (n < a.ldc) c_row[n] = 0.f;
     if (MODE == JTVAE_EPI_PLAIN && e.pre_out && n < e.ld_pre) e.pre_out[(size_t)R.m * e.ld_pre + n] = 0.f;
     if (MODE == JTVAE_EPI_GRU_BLEND && n < e.ld_aux) e.out2[aux_off + n] = 0.f;
+    if (MODE == EPI_GRU_BWD && n < e.ld_aux) {
+      a.bw_dz[(size_t)R.i * e.ld_aux + n] = 0.f;
+      a.bw_dp[(size_t)R.i * e.ld_aux + n] = 0.f;
+      e.out2[aux_off + n] = 0.f;
+    }
     return;
   }
   if (e.bias) v += e.bias[n];
@@ -180,10 +198,19 @@ __device__ __forceinline__ void epi_store(const NtArgs& a, const EpiRow& R, int 
     const float s = e.aux1[aux_off + n];
     c_row[n] = p;
     e.out2[aux_off + n] = (R.m == e.zero_row) ? 0.f : fmaf(z, p - s, s);  // (1-z)s + zp
-  } else {  // JTVAE_EPI_MUL_ACC
+  } else if (MODE == JTVAE_EPI_MUL_ACC) {
     c_row[n] = v;
     const float* mul_row = epi_mul_row(a, R);
     if (mul_row) e.out2[aux_off + n] = fmaf(v, mul_row[n], e.out2[aux_off + n]);
+  } else {  // EPI_GRU_BWD
+    c_row[n] = v;
+    const size_t st = (size_t)R.tau * e.aux_slab_stride + aux_off + n;
+    const float d = R.m == e.zero_row ? 0.f : v;
+    const float zz = e.aux0[st], pp = e.aux1[st];
+    const float ss = R.tau > 0 ? a.bw_s[st] : 0.f;
+    a.bw_dz[(size_t)R.i * e.ld_aux + n] = d * (pp - ss) * zz * (1.f - zz);
+    a.bw_dp[(size_t)R.i * e.ld_aux + n] = d * zz * (1.f - pp * pp);
+    e.out2[aux_off + n] = d * (1.f - zz);
   }
 }
 
@@ -216,10 +243,11 @@ __device__ __forceinline__ void epi_store_vec(const NtArgs& a, const EpiRow (&R)
   }
   const bool c_in = n < a.ldc;
   const bool aux_in = n < e.ld_aux;
-  float4 add4[J], x0[J], x1[J];
+  float4 add4[J], x0[J], x1[J], x2[MODE == EPI_GRU_BWD ? J : 1];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     add4[j] = x0[j] = x1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == EPI_GRU_BWD) x2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!ok[j]) continue;
     if (e.add && n < e.ld_add) add4[j] = ld4(epi_add_row(a, R[j]) + n);
     if (MODE == JTVAE_EPI_GRU_BLEND && aux_in) {
@@ -229,6 +257,12 @@ __device__ __forceinline__ void epi_store_vec(const NtArgs& a, const EpiRow (&R)
     if (MODE == JTVAE_EPI_MUL_ACC && aux_in && R[j].tau >= 0) {
       x0[j] = ld4(epi_mul_row(a, R[j]) + n);
       x1[j] = ld4(e.out2 + epi_aux_off(a, R[j]) + n);
+    }
+    if (MODE == EPI_GRU_BWD && aux_in) {
+      const size_t st = (size_t)R[j].tau * e.aux_slab_stride + epi_aux_off(a, R[j]) + n;
+      x0[j] = ld4(e.aux0 + st);
+      x1[j] = ld4(e.aux1 + st);
+      if (R[j].tau > 0) x2[j] = ld4(a.bw_s + st);  // iteration 0 has s == 0 and keeps no s
     }
   }
 #pragma unroll
@@ -264,7 +298,7 @@ __device__ __forceinline__ void epi_store_vec(const NtArgs& a, const EpiRow (&R)
         if (R[j].m == e.zero_row) h = make_float4(0.f, 0.f, 0.f, 0.f);
         st4(e.out2 + epi_aux_off(a, R[j]) + n, keep_cols(h, nv));
       }
-    } else {  // JTVAE_EPI_MUL_ACC
+    } else if (MODE == JTVAE_EPI_MUL_ACC) {
       if (c_in) st4(epi_c_row(a, R[j]) + n, x);
       if (aux_in && R[j].tau >= 0) {
         float4 o;
@@ -273,6 +307,20 @@ __device__ __forceinline__ void epi_store_vec(const NtArgs& a, const EpiRow (&R)
         o.z = fmaf(x.z, x0[j].z, x1[j].z);
         o.w = fmaf(x.w, x0[j].w, x1[j].w);
         st4(e.out2 + epi_aux_off(a, R[j]) + n, o);
+      }
+    } else {  // EPI_GRU_BWD: the arithmetic of the stand-alone pointwise kernel on the value just formed
+      if (c_in) st4(epi_c_row(a, R[j]) + n, x);
+      if (aux_in) {
+        using namespace jtvae;
+        const float4 one = make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 d = R[j].m == e.zero_row ? f4zero() : x;  // backward of "* mask"
+        const float4 zz = x0[j], pp = x1[j], ss = x2[j];
+        const float4 dz = d * (pp - ss) * zz * (one - zz);
+        const float4 dp = d * zz * (one - pp * pp);
+        const float4 dsv = d * (one - zz);
+        st4(a.bw_dz + (size_t)R[j].i * e.ld_aux + n, keep_cols(dz, nv));
+        st4(a.bw_dp + (size_t)R[j].i * e.ld_aux + n, keep_cols(dp, nv));
+        st4(e.out2 + epi_aux_off(a, R[j]) + n, keep_cols(dsv, nv));
       }
     }
   }
@@ -1054,6 +1102,7 @@ int nt_setup(const float* A, int32_t lda, const float* W, int32_t ldw, float* C,
   a.lda = lda; a.ldw = ldw; a.ldc = ldc;
   a.M = M; a.N = N; a.K = K;
   a.n_tiles_n = 0; a.n_blocks = 0;
+  a.bw_s = nullptr; a.bw_dz = nullptr; a.bw_dp = nullptr;
   if (epi) {
     a.e = *epi;
   } else {
@@ -1232,6 +1281,50 @@ int jtvae_gru_update(const float* S, const float* G, int32_t ld, const float* Wz
   } else {
     a.n_blocks = ((n_rows + NT_BM - 1) / NT_BM) * a.n_tiles_n;
     hipLaunchKernelGGL(gru_update_kernel, dim3(a.n_blocks), dim3(256), 0, s, a);
+  }
+  return launch_status();
+}
+
+int jtvae_gru_bwd_dh(const float* du, const float* UrT, int32_t ldw, const float* dhdir, float* dh,
+                     const int32_t* rows, int32_t n_rows, const float* z, const float* p, const float* s,
+                     size_t slab_stride, int32_t t_iter, const int32_t* sf, float* dzpre, float* dppre, float* ds,
+                     int32_t H, int32_t ld, int32_t pad_row, void* stream) {
+  if (n_rows < 0 || H <= 0 || ld < H || ldw < H || t_iter < 0 || (slab_stride & 3)) return JTVAE_E_SHAPE;
+  if (n_rows == 0) return 0;
+  if (!du || !UrT || !dhdir || !dh || !z || !p || !s || !dzpre || !dppre || !ds) return JTVAE_E_NULL;
+  NtArgs a;
+  bool vec;
+  jtvae_epilogue_t e = jtvae_epilogue_t();
+  e.zero_row = -1;
+  e.add = dhdir;
+  e.ld_add = ld;
+  e.c_rows = rows;
+  int rc = nt_setup(du, ld, UrT, ldw, dh, ld, n_rows, H, H, &e, a, vec);
+  if (rc) return rc;
+  const bool fused = vec && a.evec && n_rows <= narrow_max_rows() && aligned16(z, ld) && aligned16(p, ld) &&
+                     aligned16(s, ld) && aligned16(dzpre, ld) && aligned16(dppre, ld) && aligned16(ds, ld);
+  if (!fused) {  // the general route: the product, then the pointwise kernel on what it wrote
+    launch_nt_any(a, vec, (hipStream_t)stream);
+    rc = launch_status();
+    if (rc) return rc;
+    return jtvae_gru_bwd_pointwise(dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre, dppre, ds, H, ld,
+                                   pad_row, stream);
+  }
+  a.e.mode = EPI_GRU_BWD;
+  a.e.aux0 = z; a.e.aux1 = p; a.e.out2 = ds; a.e.ld_aux = ld;
+  a.e.aux_sf = sf; a.e.aux_t = t_iter; a.e.aux_slab_stride = slab_stride;
+  a.e.zero_row = pad_row;
+  a.bw_s = s; a.bw_dz = dzpre; a.bw_dp = dppre;
+  ++nt_launches;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_rows <= SM_MAX_ROWS && H <= SM_KMAX) {
+    a.n_tiles_n = (H + 31) / 32;
+    a.n_blocks = ((n_rows + 31) / 32) * a.n_tiles_n;
+    hipLaunchKernelGGL((gemm_nt_small_kernel<EPI_GRU_BWD>), dim3(a.n_blocks), dim3(256), 0, st, a);
+  } else {
+    a.n_tiles_n = (H + 31) / 32;
+    a.n_blocks = ((n_rows + NT_BM - 1) / NT_BM) * a.n_tiles_n;
+    hipLaunchKernelGGL((gemm_nt_kernel<true, EPI_GRU_BWD, true, 1>), dim3(a.n_blocks), dim3(256), 0, st, a);
   }
   return launch_status();
 }

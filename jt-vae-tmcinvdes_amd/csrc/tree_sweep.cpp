@@ -48,18 +48,18 @@ int jtvae_tree_gru_backward(const jtvae_tree_bwd_t* a, void* stream) {
       rc = jtvae_gru_bwd_gather(a->h, a->uh, 0, 0, a->sf, a->active, a->Pr, a->wid, a->dg, a->ds, a->trowptr,
                                 a->tcol, rows, n, a->dh, du, a->dhdir, a->H, a->ld, stream);
       if (rc) return rc;
-      jtvae_epilogue_t e = jtvae_epilogue_t();
-      e.zero_row = -1;
-      e.add = a->dhdir;
-      e.ld_add = a->ld;
-      e.c_rows = rows;
-      rc = jtvae_gemm_nt(du, a->ld, a->UrT, a->ld, a->dh, a->ld, n, a->H, a->H, &e, stream);
-      if (rc) return rc;
     }
     float* dz = a->dz + (size_t)a->off_e[L] * a->ld;
     float* dp = a->dp + (size_t)a->off_e[L] * a->ld;
-    rc = jtvae_gru_bwd_pointwise(a->dh, a->z, a->p, a->s, 0, a->T, a->sf, rows, n, dz, dp, a->ds, a->H, a->ld,
-                                 a->pad_row, stream);
+    if (L > 0) {
+      // dh of the level's rows, and the pre-activation gradients that follow from it
+      float* du = a->du + (size_t)a->off_j[L] * a->ld;
+      rc = jtvae_gru_bwd_dh(du, a->UrT, a->ld, a->dhdir, a->dh, rows, n, a->z, a->p, a->s, 0, a->T, a->sf, dz, dp,
+                            a->ds, a->H, a->ld, a->pad_row, stream);
+    } else {
+      rc = jtvae_gru_bwd_pointwise(a->dh, a->z, a->p, a->s, 0, a->T, a->sf, rows, n, dz, dp, a->ds, a->H, a->ld,
+                                   a->pad_row, stream);
+    }
     if (rc) return rc;
     const int32_t nd = a->n_dep[L];  // leading rows of the level that read other messages
     if (nd > 0) {

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class Epilogue(C.Structure):
@@ -135,6 +135,8 @@ SIGNATURES = {
                                    _i32, _vp]),
     "jtvae_gru_bwd_pointwise": (C.c_int, [_vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32,
                                           _i32, _vp]),
+    "jtvae_gru_bwd_dh": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _vp, _vp,
+                                   _i32, _i32, _i32, _vp]),
     "jtvae_gru_bwd_gather": (C.c_int, [_vp, _vp, _sz, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp,
                                        _vp, _vp, _i32, _i32, _vp]),
     "jtvae_select_slab_rows": (C.c_int, [_vp, _vp, _sz, _vp, _i32, _i32, _i32, _vp]),
@@ -423,6 +425,16 @@ def gru_bwd_pointwise(dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre,
     _run("gru_bwd_pointwise", lib.jtvae_gru_bwd_pointwise,
          (dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre, dppre, ds, H, ld, pad_row, stream_ptr()),
          nbytes=4 * H * n_rows * 7 + 8 * n_rows)
+
+
+def gru_bwd_dh(du, UrT, ldw, dhdir, dh, rows, n_rows, z, p, s, slab_stride, t_iter, sf, dzpre, dppre, ds, H, ld,
+               pad_row=0):
+    """dh[rows] = du . UrT^T + dhdir[rows] and, from that value, the pre-activation gradients of the level: the
+    product that follows gru_bwd_gather with gru_bwd_pointwise in its epilogue."""
+    _run("gemm_nt", lib.jtvae_gru_bwd_dh,
+         (du, UrT, ldw, dhdir, dh, rows, n_rows, z, p, s, slab_stride, t_iter, sf, dzpre, dppre, ds, H, ld, pad_row,
+          stream_ptr()),
+         nbytes=4 * (H * H + n_rows * H * 9), flops=2 * n_rows * H * H, tag="bwd_dh M=%d N=%d K=%d" % (n_rows, H, H))
 
 
 def gru_bwd_gather(h, Uh, slab_stride, t_iter, sf, active, Pr, wid, dg, ds, trowptr, tcol, rows, n_rows, dUh,

@@ -159,11 +159,15 @@ class _TreeGRU:
                                      dg.data_ptr(), ds.data_ptr(), mcsr_t.rowptr.data_ptr(), mcsr_t.col.data_ptr(),
                                      E.ptr(), E.n, du_t, dhdir.data_ptr(), H, ld, nnz=bs.J[lev].nnz,
                                      dh_ext=dh.data_ptr())
-                    K.gemm_nt(du_t, ld, UrT.data_ptr(), ld, dh.data_ptr(), ld, E.n, H, H, add=dhdir.data_ptr(),
-                              ld_add=ld, c_rows=E.ptr())
                 dz_t, dp_t = K.ptr(dz, bs.offE[lev] * ld), K.ptr(dp, bs.offE[lev] * ld)
-                K.gru_bwd_pointwise(dh.data_ptr(), zs.data_ptr(), ps.data_ptr(), ss.data_ptr(), stride, T, sf_p,
-                                    E.ptr(), E.n, dz_t, dp_t, ds.data_ptr(), H, ld, pad_row)
+                if lev > 0:
+                    # dh of the level's rows, with the pointwise backward of blend / sigmoid / tanh in its epilogue
+                    K.gru_bwd_dh(du_t, UrT.data_ptr(), ld, dhdir.data_ptr(), dh.data_ptr(), E.ptr(), E.n,
+                                 zs.data_ptr(), ps.data_ptr(), ss.data_ptr(), stride, T, sf_p, dz_t, dp_t,
+                                 ds.data_ptr(), H, ld, pad_row)
+                else:
+                    K.gru_bwd_pointwise(dh.data_ptr(), zs.data_ptr(), ps.data_ptr(), ss.data_ptr(), stride, T, sf_p,
+                                        E.ptr(), E.n, dz_t, dp_t, ds.data_ptr(), H, ld, pad_row)
                 nd = bs.n_dep[lev]  # leading rows of the level that read other messages
                 if nd:
                     K.gemm_nt_pair(

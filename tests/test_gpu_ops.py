@@ -563,6 +563,66 @@ def test_gru_update_equals_the_two_products_it_replaces(K, n_rows, with_rows):
     assert (out[0][2][untouched] == 7.0).all()  # rows outside the list are not written
 
 
+@pytest.mark.parametrize("n_rows", [3, 300, 513, 4100, 12000])
+def test_gru_bwd_dh_equals_the_product_and_the_pointwise_kernel_it_replaces(K, n_rows):
+    """dh of a backward level and the pre-activation gradients that follow from it in one launch, bit for bit what
+    gemm_nt (add epilogue, scattered output rows) followed by gru_bwd_pointwise produces - for the small, the
+    tiled and the general route; the padding message among the rows, rows whose state is that of iteration 0
+    (no s), compact dz / dp and ds by message id."""
+    rs = np.random.RandomState(n_rows)
+    H, ld, T = 450, 452, 20
+    NM = n_rows + 11
+    def buf(n, scale=1.0):
+        a = np.zeros((n, ld), np.float32)
+        a[:, :H] = rs.standard_normal((n, H)).astype(np.float32) * scale
+        return torch.from_numpy(a).cuda()
+    du, UrT, dhdir = buf(n_rows, 0.5), buf(H, 0.05), buf(NM, 0.5)
+    z, p, s = buf(NM), buf(NM), buf(NM)
+    z, p = torch.sigmoid(z), torch.tanh(p)
+    z[:, H:] = 0; p[:, H:] = 0
+    r = np.sort(rs.permutation(NM)[:n_rows]).astype(np.int32)
+    r[0] = 0  # the padding message: its gradient is dropped
+    rows = torch.from_numpy(r).cuda()
+    sf = rs.randint(1, T + 3, size=NM).astype(np.int32)  # sf == 1: the row's state is that of iteration 0
+    sf_d = torch.from_numpy(sf).cuda()
+    out = []
+    for fused in (True, False):
+        dh, ds = (torch.full((NM, ld), 7.0, device="cuda") for _ in range(2))
+        dz, dp = (torch.full((n_rows, ld), 7.0, device="cuda") for _ in range(2))
+        if fused:
+            K.gru_bwd_dh(du.data_ptr(), UrT.data_ptr(), ld, dhdir.data_ptr(), dh.data_ptr(), rows.data_ptr(), n_rows,
+                         z.data_ptr(), p.data_ptr(), s.data_ptr(), 0, T, sf_d.data_ptr(), dz.data_ptr(), dp.data_ptr(),
+                         ds.data_ptr(), H, ld, 0)
+        else:
+            K.gemm_nt(du.data_ptr(), ld, UrT.data_ptr(), ld, dh.data_ptr(), ld, n_rows, H, H, add=dhdir.data_ptr(),
+                      ld_add=ld, c_rows=rows.data_ptr())
+            K.gru_bwd_pointwise(dh.data_ptr(), z.data_ptr(), p.data_ptr(), s.data_ptr(), 0, T, sf_d.data_ptr(),
+                                rows.data_ptr(), n_rows, dz.data_ptr(), dp.data_ptr(), ds.data_ptr(), H, ld, 0)
+        torch.cuda.synchronize()
+        out.append([t.cpu().numpy() for t in (dh, dz, dp, ds)])
+    for a, b, what in zip(out[0], out[1], ("dh", "dz", "dp", "ds")):
+        assert np.array_equal(a, b), what
+    dh64 = du.cpu().numpy().astype(np.float64)[:, :H] @ UrT.cpu().numpy().astype(np.float64)[:, :H].T \
+        + dhdir.cpu().numpy()[r][:, :H]
+    assert rel_err(out[0][0][r][:, :H], dh64) < 1e-5
+    d = dh64.copy()
+    d[r == 0] = 0
+    zz, pp = z.cpu().numpy().astype(np.float64)[r][:, :H], p.cpu().numpy().astype(np.float64)[r][:, :H]
+    ss = np.where((np.minimum(T, sf[r] - 1) > 0)[:, None], s.cpu().numpy().astype(np.float64)[r][:, :H], 0.0)
+    assert rel_err(out[0][1][:, :H], d * (pp - ss) * zz * (1 - zz)) < 1e-5
+    assert rel_err(out[0][2][:, :H], d * zz * (1 - pp * pp)) < 1e-5
+    assert rel_err(out[0][3][r][:, :H], d * (1 - zz)) < 1e-5
+    assert not out[0][1][:, H:].any() and not out[0][2][:, H:].any() and not out[0][3][r][:, H:].any()
+    untouched = np.setdiff1d(np.arange(NM), r)
+    assert (out[0][0][untouched] == 7.0).all() and (out[0][3][untouched] == 7.0).all()
+    assert K.lib.jtvae_gru_bwd_dh(None, UrT.data_ptr(), ld, dhdir.data_ptr(), dh.data_ptr(), None, 4, z.data_ptr(),
+                                  p.data_ptr(), s.data_ptr(), 0, T, None, dz.data_ptr(), dp.data_ptr(), ds.data_ptr(),
+                                  H, ld, 0, None) == K.E_NULL
+    assert K.lib.jtvae_gru_bwd_dh(du.data_ptr(), UrT.data_ptr(), ld, dhdir.data_ptr(), dh.data_ptr(), None, 4,
+                                  z.data_ptr(), p.data_ptr(), s.data_ptr(), 0, T, None, dz.data_ptr(), dp.data_ptr(),
+                                  ds.data_ptr(), H, 448, 0, None) == K.E_SHAPE
+
+
 def test_level_sweeps_reject_bad_arguments_and_accept_an_empty_schedule(K):
     """jtvae_tree_gru_forward / _backward: argument errors come back before any launch; a schedule without
     levels (every message settled at iteration 0) is a no-op."""
