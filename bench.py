@@ -247,10 +247,11 @@ def fresh_holder_rate(model, args, device, rank, step_on):
     from fast_jtnn_hip.prefetch import Prefetcher, warm_encoder_holders
 
     k = int(os.environ.get("JTVAE_FRESH_BATCHES", "12"))
-    batches = []
+    batches, tree_sets = [], []
     for i in range(k):
         trees = synthetic.make_batch(args.seed + 500 + 13 * i + rank, args.batch, vocab_size=args.vocab, mean_atoms=40.0)
         batches.append((T.jtenc_tensorize(trees)[0], T.mpn_tensorize([t.mol for t in trees])))
+        tree_sets.append(trees)
 
     def unseen(b):  # new tensor objects: nothing prepared is attached to them
         return tuple(tuple(x.clone() if isinstance(x, torch.Tensor) else x for x in h) for h in b)
@@ -273,12 +274,44 @@ def fresh_holder_rate(model, args, device, rank, step_on):
                     device)
     dt_pf = run(pf)
     pf.close()
+    # The same batches drawn from flat storage (the data set at rest: atoms, bonds, feature bytes, tree
+    # neighbour lists): now the tensorize work itself - the reference's per-batch datautils.tensorize - is
+    # inside the clock as well, done by the native builders straight into upload staging memory.
+    from fast_jtnn_hip import flat, flatprep
+    from fast_jtnn_hip.prefetch import default_workers
+
+    all_trees = [t for ts in tree_sets for t in ts]
+    synthetic.set_batch_nodeID(all_trees)  # node ids = positions in the whole set
+    shard = flat.shard_from_trees(all_trees)
+    ids = [np.arange(i * args.batch, (i + 1) * args.batch) for i in range(k)]
+    threads = flat.host_threads()
+    build = lambda sel: flatprep.encoder_batch(model, shard, sel, train=train, threads=threads)  # noqa: E731
+    build(ids[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for sel in ids[:4]:
+        build(sel)
+    host_ms = 1e3 * (time.perf_counter() - t0) / 4  # host time of tensorize + preparation + enqueueing the copy
+    torch.cuda.synchronize()
+    dt_flat = run(build(sel) for sel in ids)
+    workers = default_workers()
+    pf = Prefetcher(ids * 2, build, device, workers=workers)
+    dt_flat_pf = run(pf)
+    pf.close()
     return {"value_fresh_holders": round(args.batch / dt, 1), "ms_per_step_fresh_holders": round(1e3 * dt, 3),
             "value_fresh_holders_prefetched": round(args.batch / dt_pf, 1),
             "ms_per_step_fresh_holders_prefetched": round(1e3 * dt_pf, 3),
-            "what": "same step on batches never seen before: per-batch index preparation and host-to-device copies "
-                    "included (tensorize excluded) - in the stepping thread, and prepared ahead by the "
-                    "background threads of fast_jtnn_hip.prefetch"}
+            "value_from_flat_storage": round(args.batch / dt_flat, 1),
+            "value_from_flat_storage_prefetched": round(args.batch / dt_flat_pf, 1),
+            "ms_per_step_from_flat_storage_prefetched": round(1e3 * dt_flat_pf, 3),
+            "tensorize_and_prepare_host_ms_per_batch": round(host_ms, 3),
+            "host_threads": {"native_builder_threads": threads, "prefetch_workers": workers,
+                             "cpu_count": os.cpu_count()},
+            "what": "same step on batches never seen before. fresh_holders: holders come as the reference's tables "
+                    "(tensorize excluded), per-batch index preparation and host-to-device copies included - in the "
+                    "stepping thread, and prepared ahead by the background threads of fast_jtnn_hip.prefetch. "
+                    "from_flat_storage: batches are drawn from flat arrays (fast_jtnn_hip.flat) and TENSORIZE IS "
+                    "INCLUDED: native builders + preparation + copies, in the stepping thread and prefetched"}
 
 
 METRIC = {"train": "encoder fwd+bwd molecules/sec", "encode": "encoder no-grad encode molecules/sec",

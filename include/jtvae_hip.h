@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 13
+#define JTVAE_ABI_VERSION 14
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -406,6 +406,134 @@ int jtvae_prep_decoder_plan(const int32_t* src, const int32_t* dst, int64_t n_me
                             int32_t* dep_col, int64_t dep_cap, int32_t* stop_rp, int32_t* stop_col,
                             int64_t stop_cap, int32_t* stop_word, int32_t* stop_ctx, float* stop_target,
                             int32_t* pred_mess, int32_t* pred_ctx, int32_t* pred_target, int64_t* counts);
+
+/* ---- host-side tensorizers: abstract graphs -> the reference's holder tables ----------------
+ *
+ * The reference builds its holders per batch in Python (fast_jtnn/datautils.py:140-163 calling
+ * JTNNEncoder.tensorize, MPN.tensorize and JTMPN.tensorize).  Everything after the RDKit calls is index
+ * bookkeeping over small graphs; the routines below do it natively from flat arrays, for a selection `ids`
+ * (any order, repeats allowed; NULL = 0 .. n-1) of the graphs of a set, split over up to n_threads host threads
+ * (molecules are independent).  Two output forms, either may be NULL:
+ *   - `tables`: the reference's own layout, bit for bit (float feature rows, zero-padded int64 neighbour tables);
+ *   - `csr`:    what the kernels consume (byte feature rows, int32 CSR without padding slots and its transpose,
+ *               segment tables), so that the padded tables never exist.
+ * Host memory in and out, no GPU work, no stream.  JTVAE_E_RANGE: an atom / node index is out of range or a
+ * neighbour list overflows max_nb (the reference raises IndexError there). */
+
+/* Small graphs stored back to back: molecules for MPN.tensorize (fast_jtnn/mpn.py:110-161) or attachment
+ * candidates for JTMPN.tensorize (fast_jtnn/jtmpn.py:113-183).  Feature rows are the one-hot blocks of
+ * mpn.py:46-68 / jtmpn.py:48-68 as bytes. */
+typedef struct jtvae_graph_set {
+  int64_t n_graphs;
+  const int64_t* atom_ptr;   /* [n_graphs + 1] first atom of every graph                              */
+  const int64_t* bond_ptr;   /* [n_graphs + 1] first (undirected) bond of every graph                 */
+  const uint8_t* atom_feats; /* [atoms, atom_fdim]                                                    */
+  const int32_t* bonds;      /* [bonds, 2] begin atom, end atom: positions inside the graph           */
+  const uint8_t* bond_feats; /* [bonds, bond_fdim]                                                    */
+  const int32_t* atom_nid;   /* candidates: [atoms] the atom-map number of jtmpn.py:140 (0 = none,    */
+                             /* else 1-based position of a node in the owning tree); NULL: molecules  */
+  int32_t atom_fdim, bond_fdim;
+} jtvae_graph_set_t;
+
+/* The tree messages of a batch, for the candidate graphs' extra in-edges (the mess_dict of
+ * fast_jtnn/jtnn_enc.py:58-62 as arrays): message m runs src[m] -> dst[m] (batch-global node ids, m = 0 is the
+ * padding message); node_base[i] = batch-global id of the first node of the tree that selected graph i belongs to. */
+typedef struct jtvae_mess_index {
+  int64_t n_mess, n_nodes;
+  const int32_t* src;
+  const int32_t* dst;
+  const int64_t* node_base; /* [n] */
+} jtvae_mess_index_t;
+
+typedef struct jtvae_graph_tables { /* (fatoms, fbonds, agraph, bgraph, scope) of mpn.py:161 / jtmpn.py:183 */
+  float* fatoms;   /* [atoms, atom_fdim]                                        */
+  float* fbonds;   /* [bond rows, atom_fdim + bond_fdim]                        */
+  int64_t* agraph; /* [atoms, max_nb]                                           */
+  int64_t* bgraph; /* [bond rows, max_nb]                                       */
+  int64_t* scope;  /* [n, 2] (first atom, atoms)                                */
+} jtvae_graph_tables_t;
+
+typedef struct jtvae_graph_csr {
+  uint8_t* fatoms;     /* [atoms, atom_fdim]                                                      */
+  uint8_t* fbonds;     /* [bond rows, atom_fdim + bond_fdim]                                      */
+  int32_t* a_rowptr;   /* [atoms + 1]      incoming bonds (and tree messages) of every atom       */
+  int32_t* a_col;      /* capacity a_cap                                                          */
+  int32_t* b_rowptr;   /* [bond rows + 1]  the bonds a directed bond reads                        */
+  int32_t* b_col;      /* capacity b_cap                                                          */
+  int64_t a_cap, b_cap;
+  int32_t *at_rowptr, *at_col; /* transposes over the n_src = n_mess + bond rows sources (n_mess = 0 for */
+  int32_t *bt_rowptr, *bt_col; /* molecules): [n_src + 1], capacity a_cap / b_cap; NULL = not wanted     */
+  int32_t* seg;        /* [n, 2] (first atom, atoms)                                              */
+  int32_t* seg_of;     /* [atoms] graph of every atom                                             */
+  int64_t nnz[4];      /* out: entries of a, of b, and how many of each point at tree messages    */
+} jtvae_graph_csr_t;
+
+/* counts[4] = {atoms, undirected bonds, a_cap, b_cap}: sizes of what jtvae_tensorize_graphs will write for the
+ * same selection (bond rows = 2 * bonds, + 1 padding row for molecules; the caps are tight upper bounds). */
+int jtvae_tensorize_graph_counts(const jtvae_graph_set_t* set, const int64_t* ids, int64_t n,
+                                 const jtvae_mess_index_t* mess, int64_t* counts);
+
+/* mess == NULL: MPN.tensorize (directed bond ids from 1, row 0 of fbonds / bgraph is the padding row,
+ * mpn.py:112-114); else JTMPN.tensorize (bond ids from n_mess, bond rows from 0, tree-message in-edges for
+ * bonds whose atoms carry different node ids, jtmpn.py:140-162). */
+int jtvae_tensorize_graphs(const jtvae_graph_set_t* set, const int64_t* ids, int64_t n, int32_t max_nb,
+                           const jtvae_mess_index_t* mess, jtvae_graph_tables_t* tables, jtvae_graph_csr_t* csr,
+                           int32_t n_threads);
+
+/* Junction trees stored back to back (what fast_jtnn/mol_tree.py:78-121 leaves of a MolTree for the encoder:
+ * word ids and neighbour lists; the root is a tree's first node). */
+typedef struct jtvae_tree_set {
+  int64_t n_trees;
+  const int64_t* node_ptr; /* [n_trees + 1]                                                  */
+  const int32_t* wid;      /* [nodes]                                                        */
+  const int64_t* nbr_ptr;  /* [nodes + 1]                                                    */
+  const int32_t* nbr;      /* neighbour lists in order: positions inside the tree            */
+  const int64_t* cand_ptr; /* [nodes + 1] candidates of every node in a candidate set, or NULL */
+  const int32_t* label;    /* [nodes] position of the true candidate among them, or NULL     */
+} jtvae_tree_set_t;
+
+typedef struct jtvae_tree_tables { /* (fnode, fmess, node_graph, mess_graph, scope) of jtnn_enc.py:88-92 */
+  int64_t* fnode;      /* [nodes]                   */
+  int64_t* fmess;      /* [messages]                */
+  int64_t* node_graph; /* [nodes, Kn]               */
+  int64_t* mess_graph; /* [messages, Km]            */
+  int64_t* scope;      /* [n, 2]                    */
+  int32_t Kn, Km;      /* in: the widths jtvae_tensorize_tree_counts reported */
+} jtvae_tree_tables_t;
+
+typedef struct jtvae_tree_csr {
+  int32_t* wid;      /* [nodes]                                                              */
+  int32_t* src;      /* [messages] node a message leaves (fmess)                             */
+  int32_t* dst;      /* [messages] node it arrives at                                        */
+  int32_t* n_rowptr; /* [nodes + 1]    messages arriving at every node (node_graph)          */
+  int32_t* n_col;    /* [messages - 1]                                                       */
+  int32_t* m_rowptr; /* [messages + 1] messages every message is computed from (mess_graph)  */
+  int32_t* m_col;    /* capacity m_cap                                                       */
+  int64_t m_cap;
+  int32_t* sf;       /* [messages] or NULL: iteration from which a message keeps its value   */
+                     /* (see jtvae_prep_stable_from, uncapped: 1 << 30 on a cycle)           */
+  int32_t* roots;    /* [n] or NULL: first node of every tree                                */
+  int64_t nnz;       /* out: entries of m                                                    */
+  int32_t max_sf;    /* out: largest sf (0 without messages)                                 */
+} jtvae_tree_csr_t;
+
+/* counts[5] = {nodes, messages incl. the padding message, Kn, Km, m_cap}. */
+int jtvae_tensorize_tree_counts(const jtvae_tree_set_t* set, const int64_t* ids, int64_t n, int64_t* counts);
+
+/* JTNNEncoder.tensorize after set_batch_nodeID (fast_jtnn/jtnn_enc.py:44-92, datautils.py:166-172): nodes are
+ * numbered tree by tree in selection order, messages node by node in neighbour order from 1. */
+int jtvae_tensorize_trees(const jtvae_tree_set_t* set, const int64_t* ids, int64_t n, jtvae_tree_tables_t* tables,
+                          jtvae_tree_csr_t* csr, int32_t n_threads);
+
+/* The candidate list of a training batch (fast_jtnn/datautils.py:150-161) and the segments of the assembly
+ * loss (fast_jtnn/jtnn_vae.py:116-135), from the cand_ptr / label arrays of the tree set: nodes that are leaves
+ * (one neighbour) or have exactly one candidate are skipped.  counts[2] = {candidates, segments}.  Out (second
+ * call): cand_ids [candidates] graph ids in the candidate set, batch_idx [candidates] tree position in the
+ * selection, node_base [candidates] (see jtvae_mess_index_t), seg_len / label_pos [segments] (label_pos is the
+ * index of the true candidate in the candidate list; JTVAE_E_RANGE if a segment has none). */
+int jtvae_select_candidates_counts(const jtvae_tree_set_t* set, const int64_t* ids, int64_t n, int64_t* counts);
+int jtvae_select_candidates(const jtvae_tree_set_t* set, const int64_t* ids, int64_t n, int64_t* cand_ids,
+                            int32_t* batch_idx, int64_t* node_base, int32_t* seg_len, int32_t* label_pos);
 
 #ifdef __cplusplus
 }

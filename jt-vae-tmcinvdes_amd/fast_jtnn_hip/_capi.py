@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class Epilogue(C.Structure):
@@ -95,6 +95,45 @@ class PackItem(C.Structure):
     ]
 
 
+
+class GraphSetC(C.Structure):
+    _fields_ = [("n_graphs", C.c_int64), ("atom_ptr", C.c_void_p), ("bond_ptr", C.c_void_p), ("atom_feats", C.c_void_p),
+                ("bonds", C.c_void_p), ("bond_feats", C.c_void_p), ("atom_nid", C.c_void_p), ("atom_fdim", C.c_int32),
+                ("bond_fdim", C.c_int32)]
+
+
+class MessIndexC(C.Structure):
+    _fields_ = [("n_mess", C.c_int64), ("n_nodes", C.c_int64), ("src", C.c_void_p), ("dst", C.c_void_p),
+                ("node_base", C.c_void_p)]
+
+
+class GraphTablesC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fatoms", "fbonds", "agraph", "bgraph", "scope")]
+
+
+class GraphCsrC(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("fatoms", "fbonds", "a_rowptr", "a_col", "b_rowptr", "b_col")] +
+                [("a_cap", C.c_int64), ("b_cap", C.c_int64)] +
+                [(n, C.c_void_p) for n in ("at_rowptr", "at_col", "bt_rowptr", "bt_col", "seg", "seg_of")] +
+                [("nnz", C.c_int64 * 4)])
+
+
+class TreeSetC(C.Structure):
+    _fields_ = [("n_trees", C.c_int64)] + [(n, C.c_void_p) for n in ("node_ptr", "wid", "nbr_ptr", "nbr", "cand_ptr",
+                                                                      "label")]
+
+
+class TreeTablesC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("fnode", "fmess", "node_graph", "mess_graph", "scope")] + \
+               [("Kn", C.c_int32), ("Km", C.c_int32)]
+
+
+class TreeCsrC(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("wid", "src", "dst", "n_rowptr", "n_col", "m_rowptr", "m_col")] +
+                [("m_cap", C.c_int64), ("sf", C.c_void_p), ("roots", C.c_void_p), ("nnz", C.c_int64),
+                 ("max_sf", C.c_int32)])
+
+
 PACK_MAX = 16
 E_NULL, E_SHAPE, E_ALIGN, E_RANGE, E_WORKSPACE = -1, -2, -3, -4, -5
 _i32, _vp, _sz, _i64 = C.c_int32, C.c_void_p, C.c_size_t, C.c_int64
@@ -142,7 +181,16 @@ SIGNATURES = {
     "jtvae_select_slab_rows": (C.c_int, [_vp, _vp, _sz, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_row_dot": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_row_dot_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "jtvae_tensorize_graph_counts": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "jtvae_tensorize_graphs": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32]),
+    "jtvae_tensorize_tree_counts": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "jtvae_tensorize_trees": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32]),
+    "jtvae_select_candidates_counts": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "jtvae_select_candidates": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
 }
+
+
+HOST_PREFIXES = ("jtvae_prep_", "jtvae_tensorize_", "jtvae_select_")  # host-only routines, run for milliseconds
 
 
 def _load():
@@ -161,7 +209,7 @@ def _load():
         pass
     lib = _Lib()
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(host if name.startswith("jtvae_prep_") else launch, name)  # AttributeError if not exported
+        fn = getattr(host if name.startswith(HOST_PREFIXES) else launch, name)  # AttributeError if not exported
         fn.restype = res
         fn.argtypes = args
         setattr(lib, name, fn)

@@ -25,11 +25,13 @@ def shard_path(prefix: str, rank: int, world: int) -> str:
 
 
 def encode_bulk(model, n_items: int, make_holders: Callable[[int, int], Tuple], batch_size: int, prefix: str,
-                what: str = "vectors", rank: int = 0, world: int = 1, prefetch: int = 2) -> str:
+                what: str = "vectors", rank: int = 0, world: int = 1, prefetch: int = 2, shard=None) -> str:
     """Encode items ``[lo, hi)`` of this rank and write them to its shard; returns the shard's path.
 
     ``make_holders(lo, hi)`` returns ``(jtenc_holder, mpn_holder)`` of items ``lo..hi-1`` (the
-    reference's ``tensorize(..., assm=False)`` output, fast_jtnn/datautils.py:140-163).
+    reference's ``tensorize(..., assm=False)`` output, fast_jtnn/datautils.py:140-163).  With ``shard``
+    (a ``flat.FlatShard`` holding the items) ``make_holders`` is not used: the holders of a batch are built
+    from the flat arrays by the native builders, in the prefetch threads.
     ``what``: ``"vectors"`` stores ``cat(tree_vecs, mol_vecs)`` ``[n, 2H]`` (what ``encode_from_smiles``
     returns), ``"mean"`` the latent means ``[n, latent]`` of ``encode_latent``.
     ``prefetch``: batches that a background thread tensorizes, prepares and uploads ahead of the encoder
@@ -57,17 +59,28 @@ def encode_bulk(model, n_items: int, make_holders: Callable[[int, int], Tuple], 
             out[row:row + n] = staging[i][:n].numpy()
             pending = None
 
+    def from_flat(b_lo, b_hi):
+        from . import flatprep
+
+        return flatprep.encoder_batch(model, shard, np.arange(b_lo, b_hi), train=False)
+
     def holders():
         for b_lo in range(lo, hi, batch_size):
             b_hi = min(b_lo + batch_size, hi)
-            yield (b_lo, b_hi) + tuple(make_holders(b_lo, b_hi))
+            if shard is not None and prefetch > 0:
+                yield (b_lo, b_hi)  # built in a prefetch thread
+            else:
+                yield (b_lo, b_hi) + tuple((from_flat if shard is not None else make_holders)(b_lo, b_hi))
 
     source = holders()
     if prefetch > 0:
         from .prefetch import Prefetcher, warm_encoder_holders
 
-        source = Prefetcher(source, lambda it: warm_encoder_holders(model, it[2], it[3], train=False), dev,
-                            depth=prefetch)
+        if shard is not None:
+            prepare = lambda it: it + tuple(from_flat(*it))  # noqa: E731
+        else:
+            prepare = lambda it: warm_encoder_holders(model, it[2], it[3], train=False)  # noqa: E731
+        source = Prefetcher(source, prepare, dev, depth=prefetch)
     was_training = model.training
     model.eval()
     try:

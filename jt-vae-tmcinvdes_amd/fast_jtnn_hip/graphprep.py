@@ -134,6 +134,18 @@ class _UploadBatch:
         self.chunks[-1][2] = used + n4
         return dev[used:used + n]
 
+    def reserve(self, n_bytes: int):
+        """(host bytes, device bytes) of a 16-byte aligned block of the staging memory that the caller fills in
+        place before ``flush`` (the native builders write their results straight into it)."""
+        n4 = (int(n_bytes) + 15) // 16 * 4
+        if not self.chunks or self.chunks[-1][2] + n4 > self.chunks[-1][0].numel():
+            size = max(self.CHUNK, n4)
+            self.chunks.append([torch.empty(size, dtype=torch.int32, pin_memory=True),
+                                _new_device_tensor(torch.empty(size, dtype=torch.int32, device=self.device)), 0])
+        host, dev, used = self.chunks[-1]
+        self.chunks[-1][2] = used + n4
+        return host.numpy()[used:used + n4].view(np.uint8)[:n_bytes], dev[used:used + n4].view(torch.uint8)[:n_bytes]
+
     def flush(self):
         for host, dev, used in self.chunks:
             if used:
@@ -421,27 +433,36 @@ def _prepare_tree(holder, device, vocab_size: int) -> TreePrep:
     roots = np.asarray([st for st, _ in scope], dtype=np.int64)
     check_range(roots, nn_, "scope")
     r_rp, r_col = padded_to_csr(ng[roots], nm)
-    nb = roots.shape[0]
+    return _tree_prep_from_csr(fn, fm, roots, m_rp, m_col, r_rp, r_col, device, vocab_size,
+                               _settling_iterations(mess_graph, m_rp, m_col))
 
+
+def _tree_prep_from_csr(fn, fm, roots, m_rp, m_col, r_rp, r_col, device, vocab_size: int, sf_true,
+                        dev_csr=None) -> TreePrep:
+    """fn: word of every node, fm: source node of every message, roots: first node of every tree; m / r: CSR of the
+    messages each message reads / that arrive at each root; sf_true: uncapped settling iteration of every
+    message.  dev_csr: DeviceCSR forms of m and r when the arrays already sit in upload staging memory."""
+    nn_, nm, nb = fn.shape[0], fm.shape[0], roots.shape[0]
     words, wid_node = _unique_bounded(fn, vocab_size)
     nw = words.shape[0]
     wid_m = wid_node[fm]
     wid_root = wid_node[roots]
     w_rp = np.arange(nw + 1, dtype=np.int64)
     ar = np.arange(nb + 1, dtype=np.int64)
+    mcsr, rcsr = dev_csr if dev_csr is not None else (upload_csr(m_rp, m_col, device), upload_csr(r_rp, r_col, device))
     # forward-only form; ensure_training() adds the transposes and the per-word groupings
     return TreePrep(
         n_nodes=nn_, n_mess=nm, n_trees=nb, n_words=nw,
         words=_dev_i32(words, device),
         word_csr=upload_csr(w_rp, words, device), word_csr_t=None,
         wid_m=_dev_i32(wid_m, device), wid_root=_dev_i32(wid_root, device),
-        mcsr=upload_csr(m_rp, m_col, device), mcsr_t=None,
-        rcsr=upload_csr(r_rp, r_col, device), rcsr_t=None,
+        mcsr=mcsr, mcsr_t=None,
+        rcsr=rcsr, rcsr_t=None,
         ident=upload_csr(ar, ar[:-1], device),
         key_m_pieces=None, key_m=None, key_r_pieces=None, key_r=None,
         vocab_size=vocab_size,
         host=dict(m_rp=m_rp, m_col=m_col, mt_rp=None, mt_col=None, wid_m=wid_m, wid_root=wid_root, words=words,
-                  r_rp=r_rp, r_col=r_col, device=device, sf_true=_settling_iterations(mess_graph, m_rp, m_col)),
+                  r_rp=r_rp, r_col=r_col, device=device, sf_true=sf_true),
         schedules={},
     )
 

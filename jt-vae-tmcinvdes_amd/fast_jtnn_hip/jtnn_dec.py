@@ -135,8 +135,6 @@ def decoder_plan_from_holder(jtenc_holder) -> DecoderPlan:
     """The same plan from the junction-tree holder (fnode, fmess, node_graph, mess_graph, scope) that
     ``JTNNEncoder.tensorize`` built for the batch: the tables hold every tree's nodes, neighbour order and
     root, so no tree object is touched and the walk runs in the native library."""
-    from . import _capi as K
-
     fnode, fmess, node_graph, _, scope = jtenc_holder
     wid = graphprep._to_np(fnode).astype(np.int32)
     src = graphprep._to_np(fmess).astype(np.int32)
@@ -146,6 +144,16 @@ def decoder_plan_from_holder(jtenc_holder) -> DecoderPlan:
     nz = ng != 0
     dst[ng[nz]] = np.repeat(np.arange(ng.shape[0], dtype=np.int32), nz.sum(axis=1))  # message m arrives at node y
     roots = np.asarray([st for st, _ in scope], dtype=np.int32)
+    return decoder_plan_from_arrays(wid, src, dst, roots)
+
+
+def decoder_plan_from_arrays(wid, src, dst, roots) -> DecoderPlan:
+    """The plan from the batch's message arrays: word of every node, source and target node of every directed
+    tree edge (entry 0 = padding message), first node of every tree."""
+    from . import _capi as K
+
+    wid, src = np.ascontiguousarray(wid, dtype=np.int32), np.ascontiguousarray(src, dtype=np.int32)
+    n_mess = src.shape[0]
     a = K.prep_decoder_plan(src, dst, wid, roots)
     mess_word = wid[src].astype(np.int64)
     return DecoderPlan(n_trees=len(roots), n_mess=n_mess, mess_word=mess_word, dep_rp=a["dep_rp"],
@@ -189,10 +197,11 @@ class JTNNDecoder(nn.Module):
                                          self.W_r.bias, self.U_r.weight, None, self.W_h.weight, self.W_h.bias,
                                          prep, torch.is_grad_enabled())
 
-    def forward(self, mol_batch, x_tree_vecs, jtenc_holder=None):
+    def forward(self, mol_batch, x_tree_vecs, jtenc_holder=None, sync=True):
         """``jtenc_holder``: the junction-tree holder of the same batch, if the caller has it (JTNNVAE.forward
         does): the trace tables then come from it natively and are kept with it; without it they are built
-        from the tree objects."""
+        from the tree objects.  ``sync=False`` returns the two accuracies as 0-d device tensors instead of
+        Python floats (the caller fetches them together with its other scalars in one copy)."""
         dev = self.W_z.weight.device
         if dev.type != "cuda":
             raise RuntimeError("fast_jtnn_hip.JTNNDecoder runs on an MI355X only (module is on %s); there is no "
@@ -241,5 +250,7 @@ class JTNNDecoder(nn.Module):
             stop_scores = self.aggregate(stop_hiddens, stop_ctx, x_tree_vecs, "stop").squeeze(-1)
             stop_loss = F.binary_cross_entropy_with_logits(stop_scores, stop_target, reduction="sum") / B
             stop_acc = ((stop_scores >= 0).float() == stop_target).float().sum() / stop_target.nelement()
+            if not sync:
+                return pred_loss, stop_loss, pred_acc, stop_acc
             accs = torch.stack([pred_acc, stop_acc]).tolist()  # one host sync for both
         return pred_loss, stop_loss, accs[0], accs[1]

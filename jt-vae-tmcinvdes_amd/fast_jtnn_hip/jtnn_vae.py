@@ -48,17 +48,19 @@ class _SegmentCE(torch.autograd.Function):
         return dsc * dloss, None, None
 
 
-def segment_cross_entropy(scores: torch.Tensor, seg_len: torch.Tensor, label_pos: torch.Tensor):
+def segment_cross_entropy(scores: torch.Tensor, seg_len: torch.Tensor, label_pos: torch.Tensor, seg_ptr=None):
     """Sum over segments of CrossEntropy(scores[segment], label) and the number of segments
     whose label scores highest - the loop of fast_jtnn/jtnn_vae.py:116-135 as one kernel, without
     one launch and one host sync per tree node.
 
-    scores [NC]; seg_len [S] candidates per node (consecutive); label_pos [S] global index of the label.
+    scores [NC]; seg_len [S] candidates per node (consecutive); label_pos [S] global index of the label;
+    seg_ptr: int32 [S + 1] on the device if the caller has it already (seg_len is then not read).
     """
     if scores.device.type != "cuda":
         raise RuntimeError("segment_cross_entropy runs on the GPU only (got %s)" % scores.device)
-    seg_ptr = torch.zeros(seg_len.shape[0] + 1, dtype=torch.int32, device=scores.device)
-    seg_ptr[1:] = torch.cumsum(seg_len.to(scores.device), 0)
+    if seg_ptr is None:
+        seg_ptr = torch.zeros(seg_len.shape[0] + 1, dtype=torch.int32, device=scores.device)
+        seg_ptr[1:] = torch.cumsum(seg_len.to(scores.device), 0)
     loss, hits = _SegmentCE.apply(scores, seg_ptr, label_pos.to(device=scores.device, dtype=torch.int32))
     return loss, hits.sum()
 
@@ -204,7 +206,8 @@ class JTNNVAE(nn.Module):
         # the bilinear form once per molecule, looked up per candidate inside the kernel
         return _RowDot.apply(self.A_assm(x_mol_vecs), cand_vecs, own[0], own[1])
 
-    def assm(self, mol_batch, jtmpn_holder, x_mol_vecs, x_tree_mess):  # jtnn_vae.py:105-138
+    def assm(self, mol_batch, jtmpn_holder, x_mol_vecs, x_tree_mess, sync=True):  # jtnn_vae.py:105-138
+        """``sync=False``: the accuracy comes back as a 0-d device tensor, not a float (no host wait here)."""
         scores = self.assm_scores(jtmpn_holder, x_mol_vecs, x_tree_mess)
         dev = scores.device
 
@@ -216,16 +219,42 @@ class JTNNVAE(nn.Module):
                         label_pos.append(tot + node.cands.index(node.label))
                         seg_len.append(len(node.cands))
                         tot += len(node.cands)
-            return torch.tensor(seg_len, device=dev), torch.tensor(label_pos, device=dev), len(seg_len)
+            import numpy as np
+            ptr = np.zeros(len(seg_len) + 1, dtype=np.int64)
+            np.cumsum(seg_len, out=ptr[1:])
+            with graphprep.packed_uploads(dev):
+                t = (graphprep._dev_i32(ptr, dev), graphprep._dev_i32(np.asarray(label_pos + [0], dtype=np.int64), dev))
+            return t[0], t[1][:len(seg_len)], len(seg_len), tot
 
         key = jtmpn_holder[1]  # one batch_idx tensor per batch: its segments do not change between steps
-        seg_len, label_pos, cnt = graphprep.cached_prep(key, ("assm_segments", str(dev)), segments) \
+        seg_ptr, label_pos, cnt, total = graphprep.cached_prep(key, ("assm_segments", str(dev)), segments) \
             if isinstance(key, torch.Tensor) else segments()
-        if int(seg_len.sum()) != scores.shape[0]:
-            raise ValueError("candidate segments cover %d scores, the holder has %d" % (int(seg_len.sum()),
-                                                                                   scores.shape[0]))
-        loss, acc = segment_cross_entropy(scores, seg_len, label_pos)
-        return loss / len(mol_batch), acc.item() * 1.0 / cnt
+        if total != scores.shape[0]:  # host numbers: no device round trip
+            raise ValueError("candidate segments cover %d scores, the holder has %d" % (total, scores.shape[0]))
+        loss, acc = segment_cross_entropy(scores, None, label_pos, seg_ptr=seg_ptr)
+        if cnt == 0:
+            raise ZeroDivisionError("no tree node of the batch has more than one candidate")  # jtnn_vae.py:138
+        acc = acc.float() / cnt
+        return loss / len(mol_batch), (acc.item() if sync else acc)
+
+    def _decode_and_assemble(self, x_batch, x_jtenc_holder, x_jtmpn_holder, z_tree_vecs, z_mol_vecs, x_tree_mess):
+        """Decoder and assembly terms with their accuracies as 0-d device tensors: nothing here waits for the GPU."""
+        if isinstance(getattr(self, "decoder", None), JTNNDecoder):
+            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs, x_jtenc_holder, sync=False)
+        elif hasattr(self, "decoder"):
+            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs)
+        else:
+            word_loss = topo_loss = z_tree_vecs.sum() * 0.0
+            word_acc = topo_acc = 0.0
+        assm_loss, assm_acc = self.assm(x_batch, x_jtmpn_holder, z_mol_vecs, x_tree_mess, sync=False)
+        return word_loss, topo_loss, assm_loss, [word_acc, topo_acc, assm_acc]
+
+    @staticmethod
+    def _fetch(scalars):
+        """Python floats of a list of 0-d device tensors / numbers, in ONE device-to-host copy."""
+        dev = [v for v in scalars if isinstance(v, torch.Tensor)]
+        got = iter(torch.stack([v.detach().float() for v in dev]).tolist()) if dev else iter(())
+        return [next(got) if isinstance(v, torch.Tensor) else float(v) for v in scalars]
 
     def forward(self, x_batch, beta, epsilons=None):  # jtnn_vae.py:85-103
         x_batch, x_jtenc_holder, x_mpn_holder, x_jtmpn_holder = x_batch
@@ -234,15 +263,12 @@ class JTNNVAE(nn.Module):
         z_tree_vecs, tree_kl = self.rsample(x_tree_vecs, self.T_mean, self.T_var, e_t)
         z_mol_vecs, mol_kl = self.rsample(x_mol_vecs, self.G_mean, self.G_var, e_g)
         kl_div = tree_kl + mol_kl
-        if isinstance(getattr(self, "decoder", None), JTNNDecoder):
-            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs, x_jtenc_holder)
-        elif hasattr(self, "decoder"):
-            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs)
-        else:
-            word_loss = topo_loss = z_tree_vecs.sum() * 0.0
-            word_acc = topo_acc = 0.0
-        assm_loss, assm_acc = self.assm(x_batch, x_jtmpn_holder, z_mol_vecs, x_tree_mess)
-        return word_loss + topo_loss + assm_loss + beta * kl_div, kl_div.item(), word_acc, topo_acc, assm_acc
+        word_loss, topo_loss, assm_loss, accs = self._decode_and_assemble(x_batch, x_jtenc_holder, x_jtmpn_holder,
+                                                                          z_tree_vecs, z_mol_vecs, x_tree_mess)
+        # the reference reads kl_div.item() and three accuracies one after the other (jtnn_vae.py:97-103 and the
+        # .item() calls inside decoder and assm); here they cross to the host together
+        kl, word_acc, topo_acc, assm_acc = self._fetch([kl_div] + accs)
+        return word_loss + topo_loss + assm_loss + beta * kl_div, kl, word_acc, topo_acc, assm_acc
 
 
 class JTpropVAE(JTNNVAE):
@@ -279,14 +305,8 @@ class JTpropVAE(JTNNVAE):
         z_tree_vecs, tree_kl = self.rsample(x_tree_vecs, self.T_mean, self.T_var, e_t)
         z_mol_vecs, mol_kl = self.rsample(x_mol_vecs, self.G_mean, self.G_var, e_g)
         kl_div = tree_kl + mol_kl
-        if isinstance(getattr(self, "decoder", None), JTNNDecoder):
-            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs, x_jtenc_holder)
-        elif hasattr(self, "decoder"):
-            word_loss, topo_loss, word_acc, topo_acc = self.decoder(x_batch, z_tree_vecs)
-        else:
-            word_loss = topo_loss = z_tree_vecs.sum() * 0.0
-            word_acc = topo_acc = 0.0
-        assm_loss, assm_acc = self.assm(x_batch, x_jtmpn_holder, z_mol_vecs, x_tree_mess)
+        word_loss, topo_loss, assm_loss, accs = self._decode_and_assemble(x_batch, x_jtenc_holder, x_jtmpn_holder,
+                                                                          z_tree_vecs, z_mol_vecs, x_tree_mess)
         all_vec = torch.cat([z_tree_vecs, z_mol_vecs], dim=1)
         prop_loss = self.prop_loss(self.propNN(all_vec).squeeze(), props[:, 0:2].float())
         loss = word_loss + topo_loss + assm_loss + beta * kl_div + prop_loss
@@ -299,9 +319,11 @@ class JTpropVAE(JTNNVAE):
         for v in extra.values():
             loss = loss + v
         # every logged scalar in one device-to-host copy
-        vals = torch.stack([kl_div, prop_loss] + list(extra.values())).tolist()
+        vals = self._fetch([kl_div, prop_loss] + list(extra.values()) + accs)
+        n_x = len(extra)
+        word_acc, topo_acc, assm_acc = vals[2 + n_x:]
         log_metrics = {"kl_div": vals[0], "word_acc": word_acc * 100, "topo_acc": topo_acc * 100,
                        "assm_acc": assm_acc * 100, "prop_loss": vals[1] * 100}
-        for name, v in zip(extra.keys(), vals[2:]):
+        for name, v in zip(extra.keys(), vals[2:2 + n_x]):
             log_metrics[name] = v * 100
         return loss, log_metrics

@@ -24,7 +24,7 @@ _END = object()
 
 def warm_encoder_holders(model, jtenc_holder, mpn_holder, train=True, messages_used=False):
     """Builds (and attaches to the holder tensors) what ``model.encode`` will look up: the same builders under
-    the same keys as JTNNEncoder.forward / MPN.forward use."""
+    the same keys as JTNNEncoder.forward / MPN.forward use.  Returns None: the holders themselves carry the result."""
     from . import jtnn_enc
     from .mpn import _holder_prep
 
@@ -41,19 +41,17 @@ def warm_encoder_holders(model, jtenc_holder, mpn_holder, train=True, messages_u
             graphprep.backward_schedule(prep, sched, all_messages=messages_used)
         return prep
 
-    prep = None
     split = None
     if jtnn_enc.SCHEDULE == "once":
         # the deep-tree check JTNNEncoder.forward makes first, under the key it looks it up by
         split = graphprep.cached_prep(jtenc_holder[3], ("deep_split", model.jtnn.depth),
                                       lambda: graphprep.split_deep_trees(jtenc_holder, model.jtnn.depth))
     if split is None:
-        prep = warm_tree(jtenc_holder)
+        warm_tree(jtenc_holder)
     else:
         for sub, _, _ in split:
             warm_tree(sub)
     _holder_prep(*mpn_holder, dev, 0, train)
-    return prep
 
 
 def warm_training_batch(model, x_batch):
@@ -71,7 +69,6 @@ def warm_training_batch(model, x_batch):
     graphprep.cached_prep(cj[3], ("jtmpn", str(dev), n_tree), build)
     if isinstance(getattr(model, "decoder", None), JTNNDecoder):
         graphprep.cached_prep(jt[3], ("decoder_plan",), lambda: decoder_plan_from_holder(jt))
-    return x_batch
 
 
 class Prefetcher:
@@ -80,18 +77,23 @@ class Prefetcher:
 
     A feeder thread walks ``source`` (so the loader's own work is off the stepping thread too) and hands every
     item to the pool; ``prepare`` runs under the worker's own copy stream, so its host-to-device copies overlap
-    the kernels of the batch in flight; the consumer's stream waits for them (an event per item) when the item
-    is handed over, and the allocator is told that the consumer's stream reads what was uploaded.  An exception
-    raised by the source or by ``prepare`` is re-raised in the consumer at the position of the item that caused
-    it.
+    the kernels of the batch in flight.  ``prepare`` either attaches its results to the item's holder tensors and
+    returns None (the item itself is handed on), or returns what is to be handed on in the item's place (holders
+    built from flat storage).  The consumer's stream waits for the copies (an event per item) when the item is
+    handed over.  Device memory that ``prepare`` allocates is marked as read by the stream that was current when
+    the Prefetcher was made; a consumer that iterates under another stream is refused rather than left to race
+    with the allocator.  An exception raised by the source or by ``prepare`` is re-raised in the consumer at the
+    position of the item that caused it.
     """
 
-    def __init__(self, source, prepare, device, depth: int = 4, workers: int = 3):
+    def __init__(self, source, prepare, device, depth: int = 4, workers: int = None):
         from concurrent.futures import ThreadPoolExecutor
 
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("Prefetcher uploads to an MI355X; got device %s" % self.device)
+        if workers is None:
+            workers = default_workers()
         self.source, self.prepare = source, prepare
         self.q = queue.Queue(maxsize=max(1, depth))
         self.consumer = torch.cuda.current_stream(self.device)
@@ -106,29 +108,34 @@ class Prefetcher:
             torch.cuda.set_device(self.device)
             self.tls.stream = torch.cuda.Stream(device=self.device)
         with torch.cuda.stream(self.tls.stream), graphprep.consumer_stream(self.consumer):
-            self.prepare(item)  # attaches its results to the item's holder tensors
+            out = self.prepare(item)  # attaches its results to the item's holder tensors, or returns new holders
             ev = torch.cuda.Event()
             ev.record(self.tls.stream)
-        return ev
+        return ev, item if out is None else out
 
     def _feed(self):
         try:
             for item in self.source:
                 if self.stop:
                     break
-                self.q.put((item, self.pool.submit(self._prepare, item), None))
-            self.q.put((None, None, _END))
+                self.q.put((self.pool.submit(self._prepare, item), None))
+            self.q.put((None, _END))
         except BaseException as e:  # handed to the consumer
-            self.q.put((None, None, e))
+            self.q.put((None, e))
 
     def __iter__(self):
         while True:
-            item, fut, tag = self.q.get()
+            fut, tag = self.q.get()
             if tag is _END:
                 return
             if tag is not None:
                 raise tag
-            torch.cuda.current_stream(self.device).wait_event(fut.result())
+            ev, item = fut.result()
+            cur = torch.cuda.current_stream(self.device)
+            if cur != self.consumer:
+                raise RuntimeError("Prefetcher was created under stream %s and is iterated under %s: the uploaded "
+                                   "tables are only protected for the former" % (self.consumer, cur))
+            cur.wait_event(ev)
             yield item
 
     def close(self):
@@ -147,3 +154,12 @@ class Prefetcher:
     def __exit__(self, *exc):
         self.close()
         return False
+
+
+def default_workers() -> int:
+    """Background preparation threads per rank: 3 where the host has the cores for every rank of the node to run
+    that many (a worker also spends part of its time inside multi-threaded native builders), fewer otherwise."""
+    import os
+
+    world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    return max(1, min(3, (os.cpu_count() or 1) // (2 * world)))

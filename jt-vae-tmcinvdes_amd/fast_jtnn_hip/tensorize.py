@@ -1,15 +1,17 @@
-"""Index builders: abstract graphs -> the reference's holder tuples, vectorised.
+"""Index builders: abstract graphs -> the reference's holder tuples.
 
-Output layout is the reference's, bit for bit (checked against its own
-``JTNNEncoder.tensorize_nodes`` and against a loop-by-loop restatement of the two
-RDKit-bound tensorizers): 1-based directed bond ids with a zero padding row for
-the molecular graphs (fast_jtnn/mpn.py:112-161), message ids in node/neighbour
-order with trailing zero padding for the trees (fast_jtnn/jtnn_enc.py:54-92),
-bond ids offset by the number of tree messages for the candidate graphs
+Output layout is the reference's, bit for bit (checked against the tables its own tensorizers produce,
+tests/golden): 1-based directed bond ids with a zero padding row for the molecular graphs
+(fast_jtnn/mpn.py:112-161), message ids in node/neighbour order with trailing zero padding for the trees
+(fast_jtnn/jtnn_enc.py:54-92), bond ids offset by the number of tree messages for the candidate graphs
 (fast_jtnn/jtmpn.py:113-183).
 
-Inputs are feature arrays and bond lists; producing those from SMILES is RDKit
-work that stays with the caller.
+``mpn_tensorize``, ``jtenc_tensorize(_nodes)``, ``jtmpn_tensorize`` and ``tensorize`` flatten the objects they
+are given (``flat.py``) and call the native builders of ``libjtvae_hip.so``; the ``*_np`` functions are the same
+tables stated in numpy, kept as checkers of the native ones and for inputs the flat form does not hold
+(feature values that are not whole numbers).
+
+Inputs are feature arrays and bond lists; producing those from SMILES is RDKit work that stays with the caller.
 """
 from __future__ import annotations
 
@@ -37,8 +39,8 @@ def _ragged_to_padded(owner: np.ndarray, value: np.ndarray, n_rows: int, width: 
     return out
 
 
-def mpn_tensorize(mols: Sequence):
-    """(fatoms, fbonds, agraph, bgraph, scope) as fast_jtnn/mpn.py:110-161 builds them."""
+def mpn_tensorize_np(mols: Sequence):
+    """numpy statement of mpn_tensorize."""
     n_atoms = np.asarray([m.atom_feats.shape[0] for m in mols], dtype=np.int64)
     n_bonds = np.asarray([m.bonds.shape[0] for m in mols], dtype=np.int64)
     atom_off = np.concatenate([[0], np.cumsum(n_atoms)])
@@ -72,17 +74,8 @@ def mpn_tensorize(mols: Sequence):
             torch.from_numpy(bgraph), scope)
 
 
-def jtenc_tensorize(tree_batch: Sequence):
-    node_batch: List = []
-    scope = []
-    for tree in tree_batch:
-        scope.append((len(node_batch), len(tree.nodes)))
-        node_batch.extend(tree.nodes)
-    return jtenc_tensorize_nodes(node_batch, scope)
-
-
-def jtenc_tensorize_nodes(node_batch: Sequence, scope):
-    """((fnode, fmess, node_graph, mess_graph, scope), mess_dict) as fast_jtnn/jtnn_enc.py:54-92."""
+def jtenc_tensorize_nodes_np(node_batch: Sequence, scope):
+    """numpy statement of jtenc_tensorize_nodes."""
     fnode = np.asarray([x.wid for x in node_batch], dtype=np.int64)
     xs, ys = [], []
     for x in node_batch:
@@ -130,8 +123,8 @@ def jtenc_tensorize_nodes(node_batch: Sequence, scope):
             torch.from_numpy(mess_graph), scope), mess_dict
 
 
-def jtmpn_tensorize(cand_batch: Sequence, mess_dict):
-    """(fatoms, fbonds, agraph, bgraph, scope) as fast_jtnn/jtmpn.py:113-183."""
+def jtmpn_tensorize_np(cand_batch: Sequence, mess_dict):
+    """numpy statement of jtmpn_tensorize."""
     total_mess = len(mess_dict) + 1
     n_atoms = np.asarray([c.atom_feats.shape[0] for c in cand_batch], dtype=np.int64)
     atom_off = np.concatenate([[0], np.cumsum(n_atoms)])
@@ -176,3 +169,111 @@ def jtmpn_tensorize(cand_batch: Sequence, mess_dict):
         bgraph = np.where(keep, cand, 0)
     return (torch.from_numpy(fatoms), torch.from_numpy(fbonds), torch.from_numpy(agraph),
             torch.from_numpy(bgraph), scope)
+
+
+# ---- the native builders behind the reference's names ---------------------------------------------
+
+
+def _scope_list(scope: np.ndarray):
+    return [(int(a), int(b)) for a, b in scope.tolist()]
+
+
+def _graph_holder(tables):
+    fa, fb, ag, bg, scope = tables
+    return (torch.from_numpy(fa), torch.from_numpy(fb), torch.from_numpy(ag), torch.from_numpy(bg), _scope_list(scope))
+
+
+def mpn_tensorize(mols: Sequence):
+    """(fatoms, fbonds, agraph, bgraph, scope) as fast_jtnn/mpn.py:110-161 builds them."""
+    from . import flat
+
+    try:
+        gs = flat.graph_set_from_objects(mols)
+    except ValueError:  # feature values the byte form cannot hold
+        return mpn_tensorize_np(mols)
+    return _graph_holder(flat.graph_tables(gs, max_nb=MPN_MAX_NB))
+
+
+def jtenc_tensorize(tree_batch: Sequence):
+    """fast_jtnn/jtnn_enc.py:44-52."""
+    node_batch: List = []
+    scope = []
+    for tree in tree_batch:
+        scope.append((len(node_batch), len(tree.nodes)))
+        node_batch.extend(tree.nodes)
+    return jtenc_tensorize_nodes(node_batch, scope)
+
+
+def jtenc_tensorize_nodes(node_batch: Sequence, scope):
+    """((fnode, fmess, node_graph, mess_graph, scope), mess_dict) as fast_jtnn/jtnn_enc.py:54-92.  ``mess_dict``
+    is a read-only mapping over the message arrays (``flat.MessDict``)."""
+    from . import flat
+
+    sizes = [n for _, n in scope]
+    starts = np.asarray([st for st, _ in scope], dtype=np.int64)
+    contiguous = sum(sizes) == len(node_batch) and np.array_equal(np.cumsum([0] + sizes[:-1]), starts)
+    try:
+        if not contiguous:
+            raise ValueError("scope is not the trees back to back")
+        ts, _ = flat.tree_set_from_nodes(node_batch, sizes)
+    except ValueError:  # node ids that are not batch positions, neighbours outside their tree's scope ...
+        return jtenc_tensorize_nodes_np(node_batch, scope)
+    try:
+        (fnode, fmess, node_graph, mess_graph, _), (src, dst) = flat.tree_tables(ts)
+    except IndexError:  # a neighbour outside its own tree: the scope does not delimit the trees
+        return jtenc_tensorize_nodes_np(node_batch, scope)
+    holder = (torch.from_numpy(fnode), torch.from_numpy(fmess), torch.from_numpy(node_graph),
+              torch.from_numpy(mess_graph), scope)
+    return holder, flat.MessDict(src, dst, len(node_batch))
+
+
+def jtmpn_tensorize(cand_batch: Sequence, mess_dict):
+    """(fatoms, fbonds, agraph, bgraph, scope) as fast_jtnn/jtmpn.py:113-183."""
+    from . import flat
+
+    if not len(cand_batch):
+        return _empty_cand_holder()
+    try:
+        gs = flat.graph_set_from_objects(cand_batch, with_nid=True)
+        src, dst, n_nodes = flat.mess_arrays(mess_dict)
+    except ValueError:
+        return jtmpn_tensorize_np(cand_batch, mess_dict)
+    # atom-map number k of a candidate names node all_nodes[k - 1]; with batch-wide consecutive node ids that
+    # is all_nodes[0].idx + k - 1
+    base = np.empty(len(cand_batch), np.int64)
+    seen = {}
+    for i, c in enumerate(cand_batch):
+        key = id(c.all_nodes)
+        b = seen.get(key)
+        if b is None:
+            nodes = c.all_nodes
+            b = nodes[0].idx if len(nodes) else 0
+            if any(n.idx != b + j for j, n in enumerate(nodes)):
+                return jtmpn_tensorize_np(cand_batch, mess_dict)
+            seen[key] = b
+            n_nodes = max(n_nodes, b + len(nodes))
+        base[i] = b
+    mess = flat.candidate_mess(src, dst, n_nodes, base)
+    return _graph_holder(flat.graph_tables(gs, mess=mess, max_nb=JTMPN_MAX_NB))
+
+
+def _empty_cand_holder():
+    from .synthetic import JTMPN_ATOM_FDIM, JTMPN_BOND_FDIM
+
+    return (torch.zeros((0, JTMPN_ATOM_FDIM)), torch.zeros((0, JTMPN_ATOM_FDIM + JTMPN_BOND_FDIM)),
+            torch.zeros((0, JTMPN_MAX_NB), dtype=torch.int64), torch.zeros((0, JTMPN_MAX_NB), dtype=torch.int64), [])
+
+
+def tensorize(tree_batch: Sequence, vocab=None, assm: bool = True):
+    """The per-batch ``tensorize`` of fast_jtnn/datautils.py:140-163 on abstract trees (``tree.mol`` holds the
+    molecule's graph, ``node.cands`` the candidate graphs): returns ``(tree_batch, jtenc_holder, mpn_holder)``
+    and, with ``assm``, ``(jtmpn_holder, batch_idx)`` as a fourth item."""
+    from .synthetic import collect_candidates, set_batch_nodeID
+
+    set_batch_nodeID(tree_batch, vocab)
+    jtenc_holder, mess_dict = jtenc_tensorize(tree_batch)
+    mpn_holder = mpn_tensorize([t.mol for t in tree_batch])
+    if assm is False:
+        return tree_batch, jtenc_holder, mpn_holder
+    cands, batch_idx = collect_candidates(tree_batch)
+    return tree_batch, jtenc_holder, mpn_holder, (jtmpn_tensorize(cands, mess_dict), torch.from_numpy(batch_idx))

@@ -137,11 +137,10 @@ def main(argv=None):
 
     for epoch in range(args.epoch):
         # the next batch is tensorized, prepared and uploaded by a background thread while this one steps
-        loader = Prefetcher(synthetic_batches(args.train, V, args.batch_size, rank, world, epoch, args.conditional),
-                            lambda b: warm_training_batch(model, b), device)
-        for batch in loader:
-            tr.step(batch)
-        loader.close()
+        with Prefetcher(synthetic_batches(args.train, V, args.batch_size, rank, world, epoch, args.conditional),
+                        lambda b: warm_training_batch(model, b), device) as loader:  # closed on any exit
+            for batch in loader:
+                tr.step(batch)
     tr.save("model.epoch-%d" % tr.total_step)  # vae_train.py:146
     if world > 1:
         torch.distributed.barrier()
