@@ -39,6 +39,15 @@ _PACK_CACHE = OrderedDict()  # layout key -> (weights, their versions, packed bu
 _PACK_CACHE_MAX = 16
 
 
+def _stamp(w: torch.Tensor):
+    return (w._version, w.data_ptr(), w.device, w.dtype)
+
+
+def invalidate_packed_weights() -> None:
+    """Forget every packed weight layout (needed only after writing through ``param.data``)."""
+    _PACK_CACHE.clear()
+
+
 def pack_weights(specs):
     """GEMM operands of Linear weights, all produced by one launch.
 
@@ -47,16 +56,20 @@ def pack_weights(specs):
     operand of the dgrad GEMM).  Padding columns are zero.  Returns the buffers in order; they share one
     allocation.
 
-    The result is kept until one of the weights changes (an optimizer step bumps a tensor's version
-    counter), so inference and the two passes of a training step pack each layout once per weight update.
-    The entry holds the weight tensors themselves, which rules out a recycled object id or address.
+    The result is kept until one of the weights changes: an in-place update of the parameter (an optimizer
+    step) bumps its version counter, and a move or cast (``model.to``, ``.half()``) or a swap of ``.data``
+    changes its storage address, device or dtype - all four are part of the hit check.  What it cannot see is a
+    write THROUGH ``param.data`` into the same storage (``p.data.mul_(2)``: no version bump, same address);
+    code that does that calls ``invalidate_packed_weights()`` afterwards (``load_state_dict`` copies in place
+    on the parameter itself and is seen).  The entry holds the weight tensors themselves, which rules out a
+    recycled object id or address.
     """
     key = tuple((id(w), col0, ncols, bool(transposed)) for w, col0, ncols, transposed in specs)
     hit = _PACK_CACHE.get(key)
     if hit is not None:
-        ws, versions, bufs, store = hit
+        ws, stamps, bufs, store = hit
         if all(w is c for (w, _, _, _), c in zip(specs, ws)) and \
-                all(w._version == v for (w, _, _, _), v in zip(specs, versions)):
+                all(_stamp(w) == v for (w, _, _, _), v in zip(specs, stamps)):
             _PACK_CACHE.move_to_end(key)
             if store.is_cuda:  # a later step may run on another stream than the one that packed
                 store.record_stream(torch.cuda.current_stream(store.device))
@@ -79,7 +92,7 @@ def pack_weights(specs):
         bufs.append(buf)
         items.append((K.ptr(w, col0), w.shape[1], buf.data_ptr(), ld, w.shape[0], ncols, 1 if transposed else 0))
     K.pack_batch(items)
-    _PACK_CACHE[key] = ([w for w, _, _, _ in specs], [w._version for w, _, _, _ in specs], bufs, store)
+    _PACK_CACHE[key] = ([w for w, _, _, _ in specs], [_stamp(w) for w, _, _, _ in specs], bufs, store)
     while len(_PACK_CACHE) > _PACK_CACHE_MAX:
         _PACK_CACHE.popitem(last=False)
     return bufs
