@@ -391,6 +391,16 @@ int jtvae_prep_backward_once(const int32_t* rowptr, const int32_t* col, int64_t 
                              int64_t n_seeds, uint8_t* act, int32_t* order, int32_t* lev_off, int32_t* n_dep,
                              int64_t* deg_sum, int64_t* tdeg_sum, int64_t* counts);
 
+/* Forward plan of the compute-once GraphGRU schedule (fast_jtnn/jtnn_enc.py:111-126 with every message computed
+ * in the iteration in which it settles).  sf_true: uncapped settling iteration of every message (jtvae_prep_stable_from
+ * with a large T, or jtvae_tensorize_trees).  Out: sf [n] = min(sf_true, max(T, 1)); order [n]: messages by sf, ties in
+ * id order; keyptr [max(T,1) + 2]: group k is order[keyptr[k] .. keyptr[k+1]); u_rows: the members of order that
+ * some message reads, u_ptr [max(T,1) + 2] their group starts; nnz_ptr [max(T,1) + 2]: entries read by the groups
+ * before k. */
+int jtvae_prep_forward_once(const int32_t* rowptr, const int32_t* col, int64_t n, const int32_t* sf_true, int32_t T,
+                            int32_t* sf, int32_t* order, int32_t* keyptr, int32_t* u_rows, int32_t* u_ptr,
+                            int64_t* nnz_ptr);
+
 /* Index form of the teacher-forced decoder traces of a batch (fast_jtnn/jtnn_dec.py:59-167, dfs :299-305),
  * from the junction-tree tables: directed edge m runs src[m] -> dst[m] (ids 1 .. n_mess-1 in the numbering of
  * fast_jtnn/jtnn_enc.py:58-62; 0 = padding message), wid = word of every node, roots = first node of every
@@ -517,8 +527,10 @@ typedef struct jtvae_tree_csr {
   int32_t max_sf;    /* out: largest sf (0 without messages)                                 */
 } jtvae_tree_csr_t;
 
-/* counts[5] = {nodes, messages incl. the padding message, Kn, Km, m_cap}. */
-int jtvae_tensorize_tree_counts(const jtvae_tree_set_t* set, const int64_t* ids, int64_t n, int64_t* counts);
+/* counts[5] = {nodes, messages incl. the padding message, Kn, Km, m_cap}.  want_widths == 0 (enough for the csr
+ * form): Kn, Km come back 0 and m_cap is the cheaper bound sum over nodes of arriving x leaving messages. */
+int jtvae_tensorize_tree_counts(const jtvae_tree_set_t* set, const int64_t* ids, int64_t n, int32_t want_widths,
+                                int32_t n_threads, int64_t* counts);
 
 /* JTNNEncoder.tensorize after set_batch_nodeID (fast_jtnn/jtnn_enc.py:44-92, datautils.py:166-172): nodes are
  * numbered tree by tree in selection order, messages node by node in neighbour order from 1. */

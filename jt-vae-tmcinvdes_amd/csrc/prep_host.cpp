@@ -392,4 +392,45 @@ int jtvae_prep_backward_once(const int32_t* rowptr, const int32_t* col, int64_t 
   return 0;
 }
 
+// Forward plan of the compute-once schedule: messages grouped by the iteration in which they settle.
+int jtvae_prep_forward_once(const int32_t* rowptr, const int32_t* col, int64_t n, const int32_t* sf_true, int32_t T,
+                            int32_t* sf, int32_t* order, int32_t* keyptr, int32_t* u_rows, int32_t* u_ptr,
+                            int64_t* nnz_ptr) {
+  if (n < 0 || T < 0) return JTVAE_E_SHAPE;
+  if (!rowptr || !keyptr || !u_ptr || !nnz_ptr || (n > 0 && (!sf_true || !sf || !order || !u_rows))) return JTVAE_E_NULL;
+  const int32_t cap = T > 1 ? T : 1;
+  const int64_t nnz = n > 0 ? rowptr[n] : 0;
+  if (nnz > 0 && !col) return JTVAE_E_NULL;
+  std::vector<uint8_t> read((size_t)n, 0);
+  for (int64_t e = 0; e < nnz; ++e) {
+    if (col[e] < 0 || col[e] >= n) return JTVAE_E_RANGE;
+    read[(size_t)col[e]] = 1;
+  }
+  const int64_t nk = (int64_t)cap + 1;  // keys 0 .. cap
+  std::memset(keyptr, 0, sizeof(int32_t) * (size_t)(nk + 1));
+  for (int64_t m = 0; m < n; ++m) {
+    if (sf_true[m] < 0) return JTVAE_E_RANGE;
+    sf[m] = sf_true[m] < cap ? sf_true[m] : cap;
+    ++keyptr[sf[m] + 1];
+  }
+  for (int64_t k = 0; k < nk; ++k) keyptr[k + 1] += keyptr[k];
+  {
+    std::vector<int32_t> cur(keyptr, keyptr + nk);
+    for (int64_t m = 0; m < n; ++m) order[cur[(size_t)sf[m]]++] = (int32_t)m;
+  }
+  int64_t nu = 0, acc = 0, k = 0;
+  for (int64_t i = 0; i <= n; ++i) {
+    while (k <= nk && keyptr[k] == i) {  // group k starts here (empty groups share a start)
+      u_ptr[k] = (int32_t)nu;
+      nnz_ptr[k] = acc;
+      ++k;
+    }
+    if (i == n) break;
+    const int32_t m = order[i];
+    if (read[(size_t)m]) u_rows[nu++] = m;
+    acc += rowptr[m + 1] - rowptr[m];
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -397,34 +397,73 @@ struct LocalTree {
 
 }  // namespace
 
-int jtvae_tensorize_tree_counts(const jtvae_tree_set_t* s, const int64_t* ids, int64_t n, int64_t* counts) {
+int jtvae_tensorize_tree_counts(const jtvae_tree_set_t* s, const int64_t* ids, int64_t n, int32_t want_widths,
+                                int32_t n_threads, int64_t* counts) {
   if (!counts) return JTVAE_E_NULL;
   int rc = check_tree_set(s, ids, n);
   if (rc) return rc;
-  int64_t nodes = 0, mess = 1, kn = 1, km = 1, m_cap = 0;
-  LocalTree lt;
-  for (int64_t i = 0; i < n; ++i) {
-    const int64_t g = sel(ids, i);
-    rc = lt.build(s, g);
-    if (rc) return rc;
-    const int64_t k = s->node_ptr[g + 1] - s->node_ptr[g], ne = (int64_t)lt.mx.size();
-    nodes += k;
-    mess += ne;
-    for (int64_t y = 0; y < k; ++y) kn = std::max<int64_t>(kn, lt.in_ptr[(size_t)y + 1] - lt.in_ptr[(size_t)y]);
-    for (int64_t e = 0; e < ne; ++e) {  // (y -> z) reads the messages arriving at y that do not come from z
-      const int32_t y = lt.mx[(size_t)e], z = lt.my[(size_t)e];
-      int64_t len = 0;
-      for (int32_t q = lt.in_ptr[(size_t)y]; q < lt.in_ptr[(size_t)y + 1]; ++q) len += lt.mx[(size_t)lt.in_list[(size_t)q]] != z;
-      km = std::max(km, len);
-      m_cap += len;
+  const int T = n_threads < 1 ? 1 : (n_threads > 64 ? 64 : n_threads);
+  struct Part { int64_t nodes = 0, mess = 0, kn = 1, km = 1, m_cap = 0; };
+  std::vector<Part> parts((size_t)T);
+  auto work = [&](int t, int64_t lo, int64_t hi) -> int {
+    Part& p = parts[(size_t)t];
+    LocalTree lt;
+    std::vector<int32_t> in_cnt;
+    for (int64_t i = lo; i < hi; ++i) {
+      const int64_t g = sel(ids, i);
+      const int64_t n0 = s->node_ptr[g], k = s->node_ptr[g + 1] - n0;
+      if (!want_widths) {
+        // row (y -> z) holds at most the messages arriving at y: sum over nodes of in(y) * out(y) bounds m
+        const int64_t e0 = s->nbr_ptr[n0], ne = s->nbr_ptr[n0 + k] - e0;
+        if (ne < 0) return JTVAE_E_SHAPE;
+        if (ne > 0 && !s->nbr) return JTVAE_E_NULL;
+        in_cnt.assign((size_t)k, 0);
+        for (int64_t e = 0; e < ne; ++e) {
+          const int32_t y = s->nbr[e0 + e];
+          if (y < 0 || y >= k) return JTVAE_E_RANGE;
+          ++in_cnt[(size_t)y];
+        }
+        for (int64_t y = 0; y < k; ++y) {
+          const int64_t out = s->nbr_ptr[n0 + y + 1] - s->nbr_ptr[n0 + y];
+          // with the reverse edge present (a tree stored with both directions) each row drops one entry
+          p.m_cap += (int64_t)in_cnt[(size_t)y] * out;
+        }
+        p.nodes += k;
+        p.mess += ne;
+        continue;
+      }
+      int r = lt.build(s, g);
+      if (r) return r;
+      const int64_t ne = (int64_t)lt.mx.size();
+      p.nodes += k;
+      p.mess += ne;
+      for (int64_t y = 0; y < k; ++y) p.kn = std::max<int64_t>(p.kn, lt.in_ptr[(size_t)y + 1] - lt.in_ptr[(size_t)y]);
+      for (int64_t e = 0; e < ne; ++e) {  // (y -> z) reads the messages arriving at y that do not come from z
+        const int32_t y = lt.mx[(size_t)e], z = lt.my[(size_t)e];
+        int64_t len = 0;
+        for (int32_t q = lt.in_ptr[(size_t)y]; q < lt.in_ptr[(size_t)y + 1]; ++q) len += lt.mx[(size_t)lt.in_list[(size_t)q]] != z;
+        p.km = std::max(p.km, len);
+        p.m_cap += len;
+      }
     }
+    return 0;
+  };
+  rc = run_ranges(n, std::vector<int64_t>(), T, work);
+  if (rc) return rc;
+  Part a;
+  for (const Part& p : parts) {
+    a.nodes += p.nodes;
+    a.mess += p.mess;
+    a.kn = std::max(a.kn, p.kn);
+    a.km = std::max(a.km, p.km);
+    a.m_cap += p.m_cap;
   }
-  if (mess > INT32_MAX || nodes > INT32_MAX) return JTVAE_E_RANGE;
-  counts[0] = nodes;
-  counts[1] = mess;
-  counts[2] = kn;
-  counts[3] = km;
-  counts[4] = m_cap;
+  if (a.mess + 1 > INT32_MAX || a.nodes > INT32_MAX) return JTVAE_E_RANGE;
+  counts[0] = a.nodes;
+  counts[1] = a.mess + 1;
+  counts[2] = want_widths ? a.kn : 0;
+  counts[3] = want_widths ? a.km : 0;
+  counts[4] = a.m_cap;
   return 0;
 }
 

@@ -161,6 +161,7 @@ SIGNATURES = {
     "jtvae_prep_features_to_u8": (C.c_int, [_vp, _i64, _vp, C.POINTER(C.c_int32)]),
     "jtvae_widen_u8_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_prep_backward_once": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "jtvae_prep_forward_once": (C.c_int, [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "jtvae_prep_decoder_plan": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp,
                                           _vp, _vp, _vp, _vp, _vp]),
     "jtvae_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _vp]),
@@ -183,7 +184,7 @@ SIGNATURES = {
     "jtvae_row_dot_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
     "jtvae_tensorize_graph_counts": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "jtvae_tensorize_graphs": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32]),
-    "jtvae_tensorize_tree_counts": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "jtvae_tensorize_tree_counts": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "jtvae_tensorize_trees": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i32]),
     "jtvae_select_candidates_counts": (C.c_int, [_vp, _vp, _i64, _vp]),
     "jtvae_select_candidates": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
@@ -611,6 +612,25 @@ def prep_backward_once(rowptr, col, seeds=None):
     n_act, n_lev = int(counts[0]), int(counts[1])
     return dict(act=act[:n].view(np.bool_), order=order[:n_act], lev_off=lev_off[:n_lev + 1], n_dep=n_dep[:n_lev],
                 deg_sum=deg_sum[:n_lev], tdeg_sum=tdeg_sum[:n_lev])
+
+
+def prep_forward_once(rowptr, col, sf_true, T):
+    """Forward plan of the compute-once schedule (see jtvae_prep_forward_once): (sf, order, keyptr, u_rows, u_ptr,
+    nnz_ptr)."""
+    import numpy as np
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    sf_true = np.ascontiguousarray(sf_true, dtype=np.int32)
+    n = rowptr.size - 1
+    nk = max(int(T), 1) + 2
+    sf, order, u_rows = (np.empty(max(n, 1), np.int32) for _ in range(3))
+    keyptr, u_ptr, nnz_ptr = np.empty(nk, np.int32), np.empty(nk, np.int32), np.empty(nk, np.int64)
+    rc = lib.jtvae_prep_forward_once(_np_ptr(rowptr), _np_ptr(col), n, _np_ptr(sf_true), int(T), _np_ptr(sf),
+                                     _np_ptr(order), _np_ptr(keyptr), _np_ptr(u_rows), _np_ptr(u_ptr), _np_ptr(nnz_ptr))
+    if rc == E_RANGE:
+        raise IndexError("message dependencies out of range")
+    check(rc, "prep_forward_once")
+    return sf[:n], order[:n], keyptr, u_rows[:int(u_ptr[-1])], u_ptr, nnz_ptr
 
 
 def prep_decoder_plan(src, dst, wid, roots):

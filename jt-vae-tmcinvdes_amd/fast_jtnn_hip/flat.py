@@ -332,11 +332,12 @@ def graph_csr(gs: GraphSet, ids=None, mess: Optional[_Mess] = None, max_nb: int 
     return o
 
 
-def tree_counts(ts: TreeSet, ids=None):
+def tree_counts(ts: TreeSet, ids=None, widths: bool = True, threads: int = None):
     ids, n = _ids(ids, ts.n)
     counts = np.zeros(5, np.int64)
     c = ts.c_struct()
-    _raise(K.lib.jtvae_tensorize_tree_counts(C.addressof(c), _p(ids), n, counts.ctypes.data), "tensorize_tree_counts")
+    _raise(K.lib.jtvae_tensorize_tree_counts(C.addressof(c), _p(ids), n, int(widths), threads or host_threads(),
+                                             counts.ctypes.data), "tensorize_tree_counts")
     return tuple(int(v) for v in counts)  # nodes, messages, Kn, Km, m_cap
 
 
@@ -362,7 +363,7 @@ def tree_tables(ts: TreeSet, ids=None, threads: int = None):
 def tree_csr(ts: TreeSet, ids=None, threads: int = None, alloc=None):
     """The device-ready form of the junction trees as a dict of host arrays (see ``graph_csr`` for ``alloc``)."""
     ids, n = _ids(ids, ts.n)
-    nn, nm, _, _, m_cap = tree_counts(ts, ids)
+    nn, nm, _, _, m_cap = tree_counts(ts, ids, widths=False, threads=threads)
     alloc = alloc or (lambda name, shape, dtype: np.empty(shape, dtype))
     o = dict(wid=alloc("wid", (max(nn, 1),), np.int32), src=alloc("src", (nm,), np.int32), dst=alloc("dst", (nm,), np.int32),
              n_rowptr=alloc("n_rowptr", (nn + 1,), np.int32), n_col=alloc("n_col", (max(nm - 1, 1),), np.int32),

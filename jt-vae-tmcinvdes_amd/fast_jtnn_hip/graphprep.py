@@ -687,31 +687,28 @@ def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode, sf_tru
     dense = mode == "dense"
     once = mode == "once"
     deg = np.diff(m_rp)
-    # readers per message: from the transposed lists when they exist, else counted (inference-only holders)
-    tdeg = np.diff(mt_rp) if mt_rp is not None else np.bincount(m_col, minlength=nm)
-    if dense or T < 1 or sf_true is None:
-        sf = np.full(nm, max(T, 1), dtype=np.int64)
-    else:
-        sf = np.minimum(sf_true.astype(np.int64), max(T, 1))
     F, U = [], []
     total_nnz = int(m_col.shape[0])
     if once:
         # messages grouped by the iteration in which they settle, message order inside a group: iteration t
-        # updates group t + 1 and needs the U_r products of group t's members that somebody reads
-        keyptr, order = K.prep_group_by_key(sf.astype(np.int32), max(T, 1) + 1)
-        order = order.astype(np.int64)
+        # updates group t + 1 and needs the U_r products of group t's members that somebody reads (one native pass)
+        sf, order, keyptr, u_rows, u_ptr, nnz_ptr = K.prep_forward_once(m_rp, m_col, sf_true, T)
         order_dev = _dev_i32(order, device) if nm else None
-        read = tdeg[order] > 0
-        u_rows = order[read]
-        u_ptr = np.concatenate([[0], np.cumsum(read)])[keyptr]  # start of every group inside u_rows
         u_dev = _dev_i32(u_rows, device) if u_rows.size else None
-        nnz_ptr = np.concatenate([[0], np.cumsum(deg[order])])
+        tdeg = None
+    else:
+        # readers per message: from the transposed lists when they exist, else counted (inference-only holders)
+        tdeg = np.diff(mt_rp) if mt_rp is not None else np.bincount(m_col, minlength=nm)
+        if dense or T < 1 or sf_true is None:
+            sf = np.full(nm, max(T, 1), dtype=np.int64)
+        else:
+            sf = np.minimum(sf_true.astype(np.int64), max(T, 1))
     for t in range(T):
         if dense or t == 0:
             F.append(RowList(None, nm, total_nnz))
         elif once:
             a, b = int(keyptr[t + 1]), int(keyptr[t + 2])
-            F.append(RowList(order_dev[a:b] if b > a else None, b - a, int(nnz_ptr[b] - nnz_ptr[a])))
+            F.append(RowList(order_dev[a:b] if b > a else None, b - a, int(nnz_ptr[t + 2] - nnz_ptr[t + 1])))
         else:
             r = np.flatnonzero(sf > t)
             F.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size), int(deg[r].sum())))
@@ -729,7 +726,7 @@ def _build_tree_schedule(m_rp, m_col, mt_rp, mt_col, nm, T, device, mode, sf_tru
             U.append(RowList(_dev_i32(r, device) if r.size else None, int(r.size)))
     # the CSR arrays stay as they came (int32): the backward plans widen what they index with, when they need to
     host = dict(m_rp=m_rp, m_col=m_col, mt_rp=mt_rp, mt_col=mt_col, sf=sf, nm=nm, deg=deg.astype(np.int64),
-                tdeg=tdeg.astype(np.int64))
+                tdeg=None if tdeg is None else tdeg.astype(np.int64))
     return TreeSchedule(T=T, dense=dense, sf=_dev_i32(sf, device), sel_final=_dev_i32(np.minimum(sf, T), device),
                         F=F, U=U, bwd={}, _host=host, mode=mode)
 

@@ -225,3 +225,29 @@ def test_deep_trees_are_split_off_the_batch():
         assert np.array_equal(sub[3].numpy()[:, :k], want[3].numpy()) and not sub[3].numpy()[:, k:].any()
         assert sub[4] == want[4]
     synthetic.set_batch_nodeID(trees)
+
+
+def test_forward_once_plan_matches_numpy():
+    """jtvae_prep_forward_once against the grouping stated in numpy (stable sort by capped settling iteration)."""
+    from fast_jtnn_hip import _capi as K
+    from fast_jtnn_hip import synthetic
+    from fast_jtnn_hip import tensorize as T
+
+    trees = synthetic.make_batch(9, 40, vocab_size=31, mean_atoms=30.0)
+    mg = T.jtenc_tensorize(trees)[0][3].numpy()
+    rp, col = graphprep.padded_to_csr(mg)
+    sf_true = K.prep_stable_from(rp, col, 2 ** 30)
+    for depth in (1, 3, 20):
+        sf, order, keyptr, u_rows, u_ptr, nnz_ptr = K.prep_forward_once(rp, col, sf_true, depth)
+        cap = max(depth, 1)
+        want_sf = np.minimum(sf_true, cap)
+        assert np.array_equal(sf, want_sf)
+        want_order = np.argsort(want_sf, kind="stable")
+        assert np.array_equal(order, want_order)
+        counts = np.bincount(want_sf, minlength=cap + 1)
+        assert np.array_equal(keyptr, np.concatenate([[0], np.cumsum(counts)]))
+        read = np.bincount(col, minlength=mg.shape[0])[want_order] > 0
+        assert np.array_equal(u_rows, want_order[read])
+        assert np.array_equal(u_ptr, np.concatenate([[0], np.cumsum(read)])[keyptr])
+        deg = np.diff(rp)[want_order]
+        assert np.array_equal(nnz_ptr, np.concatenate([[0], np.cumsum(deg)])[keyptr])
