@@ -235,7 +235,7 @@ def test_forward_once_plan_matches_numpy():
 
     trees = synthetic.make_batch(9, 40, vocab_size=31, mean_atoms=30.0)
     mg = T.jtenc_tensorize(trees)[0][3].numpy()
-    rp, col = graphprep.padded_to_csr(mg)
+    rp, col = G.padded_to_csr(mg)
     sf_true = K.prep_stable_from(rp, col, 2 ** 30)
     for depth in (1, 3, 20):
         sf, order, keyptr, u_rows, u_ptr, nnz_ptr = K.prep_forward_once(rp, col, sf_true, depth)
