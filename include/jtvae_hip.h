@@ -135,8 +135,10 @@ int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const floa
  * jtvae_gemm_tn, so results are bit-identical to it.  A product whose partials need more than the
  * array holds is rejected with JTVAE_E_WORKSPACE before any launch.  All calls on one GPU share the
  * array: calls that overlap on one GPU (two streams, two threads) race; issue them on one stream.
- * The first call on a device resolves the array's address (hipGetSymbolAddress), later calls only
- * launch. */
+ * The array used is the one of the GPU that owns `stream` (of the current device for the NULL stream); the
+ * operands must live on that GPU.  The first call for a device resolves the array's address
+ * (hipGetSymbolAddress), later calls only launch.  Errors: JTVAE_E_* (negative) as everywhere, or the positive
+ * hipError_t of the address lookup / launch. */
 size_t jtvae_gemm_tn_static_max_bytes(void);
 int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
                          const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N,

@@ -1178,15 +1178,26 @@ int gemm_tn_run(const float* X, int32_t ldx, const int32_t* x_rows, const float*
   return launch_status();
 }
 
-int tn_scratch_for_current_device(void** out) {
-  int dev = -1;
-  hipError_t e = hipGetDevice(&dev);
+// The static array of the device that owns `stream` (the current device for the null stream).  hipGetSymbolAddress
+// answers for the CURRENT device, so the first call for a device makes it current for the duration of the lookup.
+int tn_scratch_for_stream(hipStream_t stream, void** out) {
+  int cur = -1, dev = -1;
+  hipError_t e = hipGetDevice(&cur);
   if (e != hipSuccess) return (int)e;
+  dev = cur;
+  if (stream) {
+    hipDevice_t d;
+    e = hipStreamGetDevice(stream, &d);
+    if (e != hipSuccess) return (int)e;
+    dev = (int)d;
+  }
   if (dev < 0 || dev >= TN_MAX_DEVICES) return JTVAE_E_RANGE;
   std::lock_guard<std::mutex> lock(tn_scratch_mutex);
   if (!tn_scratch_ptr[dev]) {
     void* p = nullptr;
+    if (dev != cur && (e = hipSetDevice(dev)) != hipSuccess) return (int)e;
     e = hipGetSymbolAddress(&p, HIP_SYMBOL(tn_scratch));
+    if (dev != cur) (void)hipSetDevice(cur);
     if (e != hipSuccess) return (int)e;
     if (!p) return JTVAE_E_NULL;
     tn_scratch_ptr[dev] = p;
@@ -1353,7 +1364,7 @@ int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, con
   // same slab plan as jtvae_gemm_tn, so the result is bit-identical to it
   if (jtvae_gemm_tn_workspace_bytes(M, N, K) > TN_SCRATCH_BYTES) return JTVAE_E_WORKSPACE;
   void* ws = nullptr;
-  const int rc = tn_scratch_for_current_device(&ws);
+  const int rc = tn_scratch_for_stream((hipStream_t)stream, &ws);
   if (rc != 0) return rc;
   // every partial the slab sum reads is written by this call's product kernel first, so the
   // contents the previous call left in the array never need clearing

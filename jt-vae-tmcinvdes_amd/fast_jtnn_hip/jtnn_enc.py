@@ -414,14 +414,16 @@ class _MessageGRUFunction(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, E, Wz, bz, Wr, br, Ur_w, bu, Wh, bh, prep, grad_on=True):
+    def forward(ctx, E, Wz, bz, Wr, br, Ur_w, bu, Wh, bh, prep, grad_on=True, depth=None):
+        """depth: number of GRU iterations (None: as many as the longest dependency chain, so that every message
+        settles; a smaller number follows the truncated recurrence iteration by iteration)."""
         dev = E.device
         H = Wr.shape[0]
         ld = K.round_ld(H)
         P = prep
         NM, NW = P.n_mess, P.n_words
         train = grad_on and any(ctx.needs_input_grad)
-        sched = graphprep.tree_schedule(P, P.depth, mode="once")
+        sched = graphprep.tree_schedule(P, P.depth if depth is None else depth, mode=SCHEDULE if depth is not None else "once")
         E_p = as_row_buffer(E, H, ld)
         Eu = K.rows(NW, ld, dev)
         K.csr_gather_sum(Eu.data_ptr(), E_p.data_ptr(), E.shape[0], None, P.word_csr.rowptr.data_ptr(),
@@ -492,7 +494,7 @@ class _MessageGRUFunction(torch.autograd.Function):
         dE = torch.empty((V, H), dtype=torch.float32, device=dev)
         K.copy_rows(dE_p.data_ptr(), ld, dE.data_ptr(), H, V, H)
         return (dE, dWz, dbz, dWr, dbr if ctx.has_br else None, dUr, dbu if ctx.has_bu else None, dWh, dbh, None,
-                None)
+                None, None)
 
 
 class GraphGRU(nn.Module):
@@ -513,17 +515,14 @@ class GraphGRU(nn.Module):
         self.W_h = nn.Linear(input_size + hidden_size, hidden_size)
 
     def forward(self, h, x, mess_graph):
-        """Inference-only entry with explicit per-message inputs (no table sharing):
-        every message is its own table row."""
+        """Stand-alone use with explicit per-message inputs (fast_jtnn/jtnn_enc.py:107-128): every message is its
+        own table row, gradients reach ``x`` and the weights.  ``h`` must be the zero start state."""
         if self.input_size != self.hidden_size:
             raise ValueError("GraphGRU kernels need input_size == hidden_size")
         dev = self.W_r.weight.device
         if dev.type != "cuda":
             raise RuntimeError("fast_jtnn_hip.GraphGRU runs on an MI355X only; there is no CPU path")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("stand-alone GraphGRU.forward is inference-only; train through JTNNEncoder")
         H = self.hidden_size
-        ld = K.round_ld(H)
         mg = graphprep._to_np(mess_graph)
         NM = mg.shape[0]
         if tuple(h.shape) != (NM, H) or tuple(x.shape) != (NM, H):
@@ -531,27 +530,20 @@ class GraphGRU(nn.Module):
         if bool((h != 0).any()):
             raise ValueError("GraphGRU kernels start from the zero state (as JTNNEncoder does, "
                              "fast_jtnn/jtnn_enc.py:25): h must be all zeros")
-        rp, col = graphprep.padded_to_csr(mg)
-        graphprep.check_range(col, NM, "mess_graph")
-        mcsr = graphprep.upload_csr(rp, col, dev)
-        wid = torch.arange(NM, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev), torch.no_grad():
-            x_p = as_row_buffer(x.to(dev), H, ld)
-            Wz, Wh = self.W_z.weight, self.W_h.weight
-            Wzx, Wzh, Whx, Whh, Wr_p, Ur_p = pack_weights(
-                [(Wz, 0, H, False), (Wz, H, H, False), (Wh, 0, H, False), (Wh, H, H, False),
-                 (self.W_r.weight, 0, H, False), (self.U_r.weight, 0, H, False)])
-            Pz, Pr, Ph = (K.rows(NM, ld, dev) for _ in range(3))
-            K.gemm_nt(x_p.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NM, H, H,
-                      bias=self.W_z.bias.data_ptr())
-            K.gemm_nt(x_p.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NM, H, H)
-            K.gemm_nt(x_p.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NM, H, H,
-                      bias=self.W_h.bias.data_ptr())
-            trp, tcol = graphprep.transpose_csr(rp, col, NM)
-            sched = graphprep.build_tree_schedule(rp, col, trp, tcol, NM, self.depth, dev, mode=SCHEDULE)
-            out, _ = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur_p,
-                                      self.U_r.bias.detach(), Whh, False)
-        return dense_view(out, H)
+        if self.depth < 1:
+            return h.to(dev) * 1.0
+        import numpy as np
+
+        def build():
+            rp, col = graphprep.padded_to_csr(mg, NM)
+            return graphprep.prepare_message_dag(np.arange(NM, dtype=np.int64), rp, col, NM, dev)
+
+        key = mess_graph if isinstance(mess_graph, torch.Tensor) else None
+        prep = build() if key is None else graphprep.cached_prep(key, ("graph_gru", str(dev)), build)
+        with torch.cuda.device(dev):
+            return _MessageGRUFunction.apply(x.to(dev), self.W_z.weight, self.W_z.bias, self.W_r.weight, None,
+                                             self.U_r.weight, self.U_r.bias, self.W_h.weight, self.W_h.bias, prep,
+                                             torch.is_grad_enabled(), self.depth)
 
 
 class JTNNEncoder(nn.Module):

@@ -16,13 +16,10 @@ gradients equals the gradient of the concatenated batch.
 from __future__ import annotations
 
 import os
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
-
-
-_PRESYNC = os.environ.get("JTVAE_ALLREDUCE_PRESYNC", "1") != "0"  # debugging switch for host-staged backends
 
 
 def dist_env() -> Tuple[int, int, int]:
@@ -148,13 +145,18 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def all_reduce_mean(self) -> None:
-        if dist.is_initialized() and dist.get_world_size() > 1:
+    def all_reduce_mean(self, force: bool = False) -> None:
+        """``force``: run the pack + collective + mean even in a process group of one rank (a rehearsal of the
+        communication path on a single GPU; the result is the step without it)."""
+        if dist.is_initialized() and (dist.get_world_size() > 1 or force):
             self.pack()
-            if self.flat.is_cuda and dist.get_backend() != "nccl" and _PRESYNC:
-                # A host-staged backend (gloo) copies the bucket to host memory from its own side stream;
-                # draining the launch stream first keeps that copy from queueing behind a whole backward pass.
-                # RCCL enqueues on the launch stream itself and needs no host wait.
+            if self.flat.is_cuda and dist.get_backend() != "nccl":
+                # gloo stages a device tensor through host memory on a stream of its own.  With two ranks sharing
+                # one GPU on this ROCm stack that all-reduce never completes when the launch stream still has work
+                # queued - with stock torch kernels alone, with one launch stream or four, on the null stream or an
+                # explicit one (scratch/gloo_stall_probe.py; both ranks park in work.wait()).  Draining the launch
+                # stream first (blocking or polling) is the one thing that avoids it, so host-staged backends get
+                # this wait.  RCCL runs the collective as a kernel on the launch stream and takes no host wait.
                 torch.cuda.current_stream(self.flat.device).synchronize()
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(dist.get_world_size())
@@ -163,11 +165,18 @@ class FlatGradBucket:
         return self.flat.numel() * self.flat.element_size()
 
 
-def all_ranks_ok(ok: bool, device=None) -> bool:
+def all_ranks_ok(ok: bool, device=None, finite: Optional[torch.Tensor] = None) -> bool:
     """Skip-bad-batch semantics of the reference trainer (fast_molvae/vae_train.py:99-108) under
-    data parallelism: a step is skipped on every rank if it failed on any."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    data parallelism: a step is skipped on every rank if it failed on any.
+
+    ``finite`` (a 0-d bool tensor on the device, e.g. ``isfinite(loss)``) joins the host-side flag on the
+    device, so that the decision costs ONE device-to-host copy per step at any world size."""
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    if not multi and finite is None:
         return ok
-    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
-    return int(flag.item()) == 0
+    bad = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device if finite is None else finite.device)
+    if finite is not None:
+        bad = bad + (~finite).to(torch.int32)
+    if multi:
+        dist.all_reduce(bad, op=dist.ReduceOp.SUM)
+    return int(bad.item()) == 0

@@ -169,13 +169,18 @@ def make_mol(rs: np.random.RandomState, mean_atoms: float = 40.0, sd_atoms: floa
 
 
 def make_tree(rs: np.random.RandomState, mol: MolGraph, vocab_size: int, node_frac: float = 0.55,
-              max_nodes: int = 40, deg_cap: int = 6) -> Tree:
+              max_nodes: int = 40, deg_cap: int = 6, shape: str = "random") -> Tree:
+    """shape "random": every new node hangs on a random earlier one (shallow, bushy trees); "chain": on the node
+    before it with probability 0.85 (long paths: many dependency levels, few messages per level)."""
     n_nodes = int(np.clip(int(round(node_frac * mol.n_atoms)), 2, max_nodes))
     nodes = [TreeNode(i + 1, int(rs.randint(0, vocab_size))) for i in range(n_nodes)]
     deg = np.zeros(n_nodes, dtype=np.int64)
     for i in range(1, n_nodes):
         cand = np.flatnonzero(deg[:i] < deg_cap)
-        p = int(cand[rs.randint(0, len(cand))])
+        if shape == "chain" and deg[i - 1] < deg_cap and rs.rand() < 0.85:
+            p = i - 1
+        else:
+            p = int(cand[rs.randint(0, len(cand))])
         nodes[p].neighbors.append(nodes[i])
         nodes[i].neighbors.append(nodes[p])
         deg[p] += 1
@@ -185,10 +190,29 @@ def make_tree(rs: np.random.RandomState, mol: MolGraph, vocab_size: int, node_fr
     return Tree(nodes=nodes, mol=mol, smiles="mol")
 
 
+def _hub_candidate(rs: np.random.RandomState, tree: Tree, node: TreeNode) -> CandGraph:
+    """A star whose centre collects the full neighbour table of the candidate encoder (fast_jtnn/jtmpn.py:39:
+    15 slots): seven bonds to atoms of neighbouring tree nodes - each brings its bond and the tree message from
+    that node - and one bond to an unlabeled atom."""
+    n = 9
+    bonds = np.asarray([(0, a) if a % 2 else (a, 0) for a in range(1, n)], dtype=np.int64)
+    atom_feats = _one_hot_blocks(rs, n, (JTMPN_ELEMS, 6, 5), 1)
+    bond_feats = np.zeros((n - 1, JTMPN_BOND_FDIM), dtype=np.float32)
+    bond_feats[np.arange(n - 1), rs.randint(0, 5, size=n - 1)] = 1.0
+    nid = np.zeros(n, dtype=np.int64)
+    nid[0] = node.nid
+    nbr_ids = [y.nid for y in node.neighbors]
+    for a in range(1, 8):
+        nid[a] = nbr_ids[(a - 1) % len(nbr_ids)]
+    return CandGraph(atom_feats, bonds, bond_feats, nid, tree.nodes, node)
+
+
 def make_candidates(rs: np.random.RandomState, tree: Tree, lo_c: int = 2, hi_c: int = 8,
-                    lo_atoms: int = 8, hi_atoms: int = 16) -> None:
+                    lo_atoms: int = 8, hi_atoms: int = 16, hub: bool = False) -> None:
     """Attach 2-8 candidate sub-graphs to every non-leaf node (shape of
-    fast_jtnn/datautils.py:150-158: leaves and single-candidate nodes are skipped)."""
+    fast_jtnn/datautils.py:150-158: leaves and single-candidate nodes are skipped).  ``hub``: the first
+    non-leaf node of the tree gets one more candidate, a star that fills all 15 neighbour slots of its centre."""
+    hub_done = not hub
     for node in tree.nodes:
         if node.is_leaf:
             node.cands = []
@@ -214,26 +238,35 @@ def make_candidates(rs: np.random.RandomState, tree: Tree, lo_c: int = 2, hi_c: 
             pick = rs.randint(0, len(nbr_ids) + 1, size=n - n_ctr)
             nid[n_ctr:] = np.where(pick == len(nbr_ids), 0, nbr_ids[np.minimum(pick, len(nbr_ids) - 1)])
             cands.append(CandGraph(atom_feats, bonds, bond_feats, nid, tree.nodes, node))
+        label = cands[int(rs.randint(0, ncand))]
+        if not hub_done:
+            cands.append(_hub_candidate(rs, tree, node))
+            hub_done = True
         node.cands = cands
-        node.label = cands[int(rs.randint(0, ncand))]
+        node.label = label
 
 
 def make_batch(seed: int, batch_size: int, vocab_size: int = 385, mean_atoms: float = 40.0,
-               with_cands: bool = False) -> List[Tree]:
+               with_cands: bool = False, tree_shape: str = "random", cand_hub: bool = False) -> List[Tree]:
     """``batch_size`` synthetic molecules with their junction trees.
 
     Defaults give the benchmark molecule: about 40 atoms / 42 bonds and about 22
     tree nodes / 42 directed tree messages, neighbour count at most 6.
+    ``tree_shape``: "random" (bushy, ~14 dependency levels at the benchmark size), "chain" (path-like, deep) or
+    "mixed" (alternating); ``cand_hub``: see ``make_candidates``.
     """
+    if tree_shape not in ("random", "chain", "mixed"):
+        raise ValueError("tree_shape must be random, chain or mixed")
     rs = np.random.RandomState(seed)
     lo = max(2, int(round(mean_atoms / 2)))
     hi = int(round(mean_atoms * 1.5))
     batch = []
-    for _ in range(batch_size):
+    for i in range(batch_size):
         mol = make_mol(rs, mean_atoms=mean_atoms, sd_atoms=mean_atoms * 0.15, lo=lo, hi=hi)
-        tree = make_tree(rs, mol, vocab_size)
+        shape = tree_shape if tree_shape != "mixed" else ("chain" if i % 2 else "random")
+        tree = make_tree(rs, mol, vocab_size, shape=shape)
         if with_cands:
-            make_candidates(rs, tree)
+            make_candidates(rs, tree, hub=cand_hub)
         batch.append(tree)
     set_batch_nodeID(batch)
     return batch

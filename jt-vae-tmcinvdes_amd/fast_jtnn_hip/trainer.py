@@ -9,7 +9,8 @@ initialisation, Adam + exponential learning-rate decay, gradient clipping at ``c
 What data parallelism adds (the reference is single-GPU): every rank steps its own shard of the
 global batch; one flat-bucket mean all-reduce joins the gradients, and it runs BEFORE the clip so
 that all ranks clip the same gradient and take the same optimizer step without another exchange; a
-batch that failed on any rank is skipped on all of them.
+batch that failed on any rank is skipped on all of them.  One rule is added at every world size: a batch whose
+loss is not finite is skipped like a failed one (the reference would step NaN gradients into the weights).
 """
 from __future__ import annotations
 
@@ -84,6 +85,7 @@ class Trainer:
         self.log = log
         self.rank, _, self.world = parallel.dist_env()
         self.device = self.params[0].device
+        self.force_collective = False  # True: the gradient all-reduce runs even with one rank (rehearsal)
 
     def forward_backward(self, batch, epsilons=None):
         """model(batch, beta) + backward into the bucket; returns (loss tensor, metrics dict)."""
@@ -99,18 +101,23 @@ class Trainer:
     def step(self, batch, epsilons=None) -> StepResult:
         self.total_step += 1
         self.bucket.zero()  # model.zero_grad() of the reference
-        loss, metrics, err = None, {}, None
+        loss, metrics, err, finite = None, {}, None, None
         try:
             loss, metrics = self.forward_backward(batch, epsilons)
-            ok = bool(torch.isfinite(loss.detach()).item()) if self.world > 1 else True
+            ok = True
+            finite = torch.isfinite(loss.detach())
         except Exception as e:  # vae_train.py:105-108: report and go on with the next batch
             if self.conditional and self.world == 1:
                 raise  # vae_train_prop.py:120-126 has no such guard
             ok, err = False, "%s: %s" % (type(e).__name__, e)
-        if not parallel.all_ranks_ok(ok, self.device if self.device.type == "cuda" else None):
+        # A non-finite loss skips the batch at every world size - an addition to the reference, which would step
+        # NaN gradients into the weights; the flag rides along with the all-rank failure flag (one host wait).
+        if not parallel.all_ranks_ok(ok, self.device if self.device.type == "cuda" else None, finite):
+            if err is None and ok:
+                err = "non-finite loss"
             self.log("Batch %d failed%s" % (self.total_step, "" if err is None else "\n" + err))
             return StepResult(False, error=err)
-        self.bucket.all_reduce_mean()
+        self.bucket.all_reduce_mean(force=self.force_collective)
         nn.utils.clip_grad_norm_(self.params, self.sched.clip_norm)
         self.optimizer.step()
         res = StepResult(True, float(loss.detach()), metrics)

@@ -46,6 +46,8 @@ class Golden:
         self.bias_scale = float(z["bias_scale"])
         self.mean_atoms = float(z["mean_atoms"])
         self.sha = str(z["weights_sha256"])
+        self.tree_shape = str(z["tree_shape"]) if "tree_shape" in z.files else "random"
+        self.cand_hub = bool(z["cand_hub"]) if "cand_hub" in z.files else False
 
     def scope(self, key):
         return [(int(a), int(b)) for a, b in self.z[key]]
@@ -79,7 +81,7 @@ class Golden:
         from fast_jtnn_hip import synthetic
 
         return synthetic.make_batch(self.seed, self.B, vocab_size=self.V, mean_atoms=self.mean_atoms,
-                                    with_cands=True)
+                                    with_cands=True, tree_shape=self.tree_shape, cand_hub=self.cand_hub)
 
 
 def projection(shape, seed):

@@ -48,7 +48,15 @@ CASES = [
     ("case1", 1, 4, 20.0, 450, 56, 20, 3, 385, 0.05),
     ("case2", 2, 8, 20.0, 450, 56, 20, 3, 385, 0.05),
     ("case3", 3, 3, 16.0, 96, 24, 4, 2, 50, 0.1),
+    # path-like trees next to bushy ones, deeper than depthT (the truncated recurrence differs from its fixed
+    # point there), and one candidate per tree whose centre atom fills all 15 neighbour slots
+    ("case4", 4, 4, 18.0, 96, 24, 4, 2, 50, 0.1, "mixed", True),
 ]
+
+
+def gen_flags(case):
+    """(tree_shape, cand_hub) of a case; the first four cases predate the flags."""
+    return (case[10], case[11]) if len(case) > 10 else ("random", False)
 
 
 def import_reference():
@@ -162,12 +170,14 @@ FWD_BETA = 0.3
 
 def training_side(ref, synthetic, case, holders, out):
     """JTNNVAE.forward / JTpropVAE.forward of the reference on the case's batch."""
-    name, seed, B, mean_atoms, H, L, dT, dG, V, bias = case
+    name, seed, B, mean_atoms, H, L, dT, dG, V, bias = case[:10]
+    shape, hub = gen_flags(case)
     jtenc_holder, mpn_holder, jtmpn_holder, batch_idx = holders
     vocab = synthetic.FakeVocab(V)
 
     def fresh_batch():  # the decoder rewires node.neighbors (jtnn_dec.py:63-64,126): one batch per call
-        return synthetic.make_batch(seed, B, vocab_size=V, mean_atoms=mean_atoms, with_cands=True)
+        return synthetic.make_batch(seed, B, vocab_size=V, mean_atoms=mean_atoms, with_cands=True, tree_shape=shape,
+                                    cand_hub=hub)
 
     model = ref.JTNNVAE(vocab, H, L, dT, dG)
     synthetic.fill_params(list(model.named_parameters()), seed=seed, bias_scale=bias)
@@ -225,6 +235,7 @@ def projection(shape, seed):
 
 
 def main():
+    only = set(sys.argv[1:])  # e.g. "case4": regenerate just that file
     ref = import_reference()
     patch_tensorizers(ref)
     from fast_jtnn_hip import synthetic
@@ -232,8 +243,12 @@ def main():
 
     torch.set_num_threads(8)
     for case in CASES:
-        name, seed, B, mean_atoms, H, L, dT, dG, V, bias = case
-        batch = synthetic.make_batch(seed, B, vocab_size=V, mean_atoms=mean_atoms, with_cands=True)
+        name, seed, B, mean_atoms, H, L, dT, dG, V, bias = case[:10]
+        if only and name not in only:
+            continue
+        shape, hub = gen_flags(case)
+        batch = synthetic.make_batch(seed, B, vocab_size=V, mean_atoms=mean_atoms, with_cands=True, tree_shape=shape,
+                                     cand_hub=hub)
         vocab = synthetic.FakeVocab(V)
         model = ref.JTNNVAE(vocab, H, L, dT, dG)
         sha = synthetic.fill_params(list(model.named_parameters()), seed=seed, bias_scale=bias)
@@ -272,6 +287,7 @@ def main():
             "meta": np.asarray([seed, B, H, L, dT, dG, V], dtype=np.int64),
             "mean_atoms": np.float64(mean_atoms),
             "bias_scale": np.float64(bias),
+            "tree_shape": np.asarray(shape), "cand_hub": np.int64(hub),
             "weights_sha256": np.asarray(sha),
             # inputs
             "fnode": jtenc_holder[0].numpy().astype(np.int32),

@@ -34,6 +34,8 @@ def test_forward_matches_reference_golden(path):
     # element by element as well (the bound above is relative to the largest entry of the tensor)
     assert np.allclose(mean.cpu().numpy(), z["mean"], rtol=1e-4, atol=1e-6)
     assert np.allclose(logvar.cpu().numpy(), z["logvar"], rtol=1e-4, atol=1e-6)
+    for got, key in ((tree_vecs, "tree_vecs"), (mol_vecs, "mol_vecs"), (cand, "cand_vecs"), (mess, "messages")):
+        assert np.allclose(got.cpu().numpy(), z[key], rtol=1e-4, atol=1e-6), key
     assert rel_err(scores.cpu().numpy(), z["scores"]) < RTOL
     assert float(mess[0].abs().max()) == 0.0  # the padding message stays exactly zero
 
@@ -459,29 +461,37 @@ def test_assembly_loss_matches_reference_loop():
     assert rel_err(sc.grad.cpu().numpy(), 0.5 * ref_scores.grad.numpy()) < 1e-5
 
 
-def test_standalone_graph_gru_matches_oracle():
+@pytest.mark.parametrize("depth,shape", [(20, "random"), (5, "chain")])
+def test_standalone_graph_gru_matches_oracle(depth, shape):
     """GraphGRU.forward(h, x, mess_graph) with explicit per-message inputs, the reference's stand-alone
-    signature (fast_jtnn/jtnn_enc.py:107-128): inference only, against the CPU oracle."""
+    signature (fast_jtnn/jtnn_enc.py:107-128), forward and backward (gradients of x and of every weight) against
+    the CPU oracle; depth 5 on path-like trees truncates the recurrence before it settles."""
     from fast_jtnn_hip import GraphGRU, synthetic, tensorize as T
     from oracle.ref_encoder import OracleGraphGRU
 
-    trees = synthetic.make_batch(8, 12, vocab_size=20)
+    trees = synthetic.make_batch(8, 12, vocab_size=20, tree_shape=shape)
     jt, _ = T.jtenc_tensorize(trees)
     mess_graph = jt[3]
-    NM, H, depth = mess_graph.shape[0], 450, 20
+    NM, H = mess_graph.shape[0], 450
     rs = np.random.RandomState(0)
-    x = torch.from_numpy(rs.standard_normal((NM, H)).astype(np.float32) * 0.3)
-    x[0] = 0  # the padding message carries no input, as in JTNNEncoder (fmess[0] = 0 -> masked anyway)
+    x0 = torch.from_numpy(rs.standard_normal((NM, H)).astype(np.float32) * 0.3)
+    x0[0] = 0  # the padding message carries no input, as in JTNNEncoder (fmess[0] = 0 -> masked anyway)
+    proj = torch.from_numpy(rs.standard_normal((NM, H)).astype(np.float32))
     hip, ora = GraphGRU(H, H, depth).cuda(), OracleGraphGRU(H, H, depth)
     synthetic.fill_params(list(hip.named_parameters()), 9, 0.1)
     synthetic.fill_params(list(ora.named_parameters()), 9, 0.1)
     with torch.no_grad():
-        got = hip(torch.zeros(NM, H), x, mess_graph)
-        want = ora(torch.zeros(NM, H), x, mess_graph)
+        got = hip(torch.zeros(NM, H), x0, mess_graph)
+        want = ora(torch.zeros(NM, H), x0, mess_graph)
     assert rel_err(got.cpu().numpy(), want.numpy()) < RTOL
+    assert np.allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-6)
     assert float(got[0].abs().max()) == 0.0
-    with pytest.raises(RuntimeError):
-        hip(torch.zeros(NM, H), x, mess_graph)  # gradients enabled: train through JTNNEncoder instead
+    xa, xb = x0.clone().cuda().requires_grad_(True), x0.clone().requires_grad_(True)
+    (hip(torch.zeros(NM, H), xa, mess_graph) * proj.cuda()).sum().backward()
+    (ora(torch.zeros(NM, H), xb, mess_graph) * proj).sum().backward()
+    assert fro_err(xa.grad.cpu().numpy(), xb.grad.numpy()) < RTOL
+    for (n, p), (_, q) in zip(hip.named_parameters(), ora.named_parameters()):
+        assert fro_err(p.grad.cpu().numpy(), q.grad.numpy()) < RTOL, n
 
 
 def test_one_deep_tree_in_a_batch_keeps_the_batch_on_the_compute_once_schedule():

@@ -67,3 +67,28 @@ def test_static_scratch_rejects_a_product_beyond_its_array():
     rc = K.lib.jtvae_gemm_tn_static(x.data_ptr(), 4096, None, x.data_ptr(), 4096, None, dW.data_ptr(), 4096, None,
                                     M, 4096, 4096, 0, K.stream_ptr())
     assert rc == K.E_WORKSPACE
+
+
+def test_static_scratch_follows_the_device_of_the_stream():
+    """The array is per GPU: a call whose stream (and operands) belong to another GPU than the current one must
+    use that GPU's array.  Needs two visible GPUs."""
+    from fast_jtnn_hip import _capi as K
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU visible")
+    rs = np.random.RandomState(3)
+    M, N, Kd = 5000, 450, 450
+    ld = K.round_ld(N)
+    with torch.cuda.device(1):
+        X = torch.from_numpy(rs.standard_normal((M, ld)).astype(np.float32)).cuda(1)
+        Y = torch.from_numpy(rs.standard_normal((M, ld)).astype(np.float32)).cuda(1)
+        dW = torch.zeros((N, Kd), device="cuda:1")
+        stream = torch.cuda.Stream(device=1)
+        torch.cuda.synchronize()
+    # current device 0, stream of device 1
+    rc = K.lib.jtvae_gemm_tn_static(X.data_ptr(), ld, None, Y.data_ptr(), ld, None, dW.data_ptr(), Kd, None, M, N, Kd, 0,
+                                    stream.cuda_stream)
+    K.check(rc, "gemm_tn_static on the second GPU")
+    stream.synchronize()
+    want = X.cpu().numpy().astype(np.float64)[:, :N].T @ Y.cpu().numpy().astype(np.float64)[:, :Kd]
+    assert np.abs(dW.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max()
