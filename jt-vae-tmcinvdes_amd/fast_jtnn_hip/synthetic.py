@@ -127,19 +127,20 @@ def _one_hot_blocks(rs: np.random.RandomState, n: int, blocks: Sequence[int], ta
 
 def _random_bonds(rs: np.random.RandomState, n: int, tree_deg_cap: int, max_deg: int, n_rings: int) -> np.ndarray:
     """Random spanning tree with a degree cap plus a few ring-closing bonds."""
-    deg = np.zeros(n, dtype=np.int64)
+    deg = [0] * n  # plain lists: the graphs are tiny and this runs once per molecule and per candidate
     bonds = []
     have = set()
+    randint, rand = rs.randint, rs.rand
     for a in range(1, n):
-        cand = np.flatnonzero(deg[:a] < tree_deg_cap)
-        p = int(cand[rs.randint(0, len(cand))])
+        cand = [i for i in range(a) if deg[i] < tree_deg_cap]
+        p = cand[randint(0, len(cand))]
         # random orientation: RDKit bonds have no preferred direction either
-        bonds.append((p, a) if rs.rand() < 0.5 else (a, p))
-        have.add((min(p, a), max(p, a)))
+        bonds.append((p, a) if rand() < 0.5 else (a, p))
+        have.add((p, a))  # p < a
         deg[p] += 1
         deg[a] += 1
     for _ in range(n_rings):
-        a, b = (int(v) for v in rs.randint(0, n, size=2))
+        a, b = (int(v) for v in randint(0, n, size=2))
         if a == b or (min(a, b), max(a, b)) in have:
             continue
         if deg[a] >= max_deg or deg[b] >= max_deg:
