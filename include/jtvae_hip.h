@@ -171,6 +171,26 @@ int jtvae_copy_rows(const float* src, int32_t ld_src, float* dst, int32_t ld_dst
 int jtvae_widen_u8_rows(const uint8_t* src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols,
                         void* stream);
 
+/* ---- linear layers on one-hot feature rows ------------------------------------------------ */
+
+/* out[r, 0:H] = bias + sum_j feats[r, j] * Wt[j, 0:H]  (terms in increasing j, zero entries skipped), columns
+ * [H, ld) = 0.  feats: [n_rows, F] bytes, dense; Wt: the transposed weight [F, ldw] (jtvae_pack_batch with
+ * transpose != 0); bias: [H] or NULL.  Replaces the Linear calls whose input is a feature matrix of one-hot blocks:
+ * W_i on fbonds (fast_jtnn/mpn.py:87, jtmpn.py:89) and the atom-feature columns of W_o (mpn.py:98-99,
+ * jtmpn.py:102-103).  A row kernel bound by the rows it writes; the table must fit in LDS
+ * (F * ldw * 4 + 4 KiB <= 150 KiB, else JTVAE_E_WORKSPACE: use jtvae_gemm_nt on the widened rows). */
+int jtvae_onehot_linear(const uint8_t* feats, int32_t n_rows, int32_t F, const float* Wt, int32_t ldw,
+                        const float* bias, float* out, int32_t ld, int32_t H, void* stream);
+
+/* dW[n, j] (+)= sum_r feats[r, j] * dOut[r, n]: the weight gradient of the layer above in nn.Linear layout
+ * ([H, lddw >= F]); autograd's addmm backward for mpn.py:87,99 / jtmpn.py:89,103.  Rows are summed in fixed order
+ * (per-block tables in LDS, then the blocks in order): bitwise reproducible.  workspace: at least
+ * jtvae_onehot_linear_bwd_workspace_bytes(n_rows, F, ld) bytes of device memory. */
+size_t jtvae_onehot_linear_bwd_workspace_bytes(int32_t n_rows, int32_t F, int32_t ld);
+int jtvae_onehot_linear_bwd(const uint8_t* feats, int32_t n_rows, int32_t F, const float* dOut, int32_t ld, int32_t H,
+                            float* dW, int32_t lddw, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                            void* stream);
+
 /* ---- neighbour gather-sum --------------------------------------------------------------- */
 
 /* out[i] = sum_{e in [rowptr[i], rowptr[i+1])} src(col[e])        for i < n_rows

@@ -182,6 +182,9 @@ SIGNATURES = {
     "jtvae_select_slab_rows": (C.c_int, [_vp, _vp, _sz, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_row_dot": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "jtvae_row_dot_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "jtvae_onehot_linear": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp]),
+    "jtvae_onehot_linear_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "jtvae_onehot_linear_bwd": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp, _sz, _vp]),
     "jtvae_tensorize_graph_counts": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "jtvae_tensorize_graphs": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32]),
     "jtvae_tensorize_tree_counts": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
@@ -405,6 +408,27 @@ def copy_rows(src, ld_src, dst, ld_dst, nrows, ncols):
 def widen_u8_rows(src, dst, ld_dst, nrows, ncols):
     _run("widen_u8_rows", lib.jtvae_widen_u8_rows, (src, dst, ld_dst, nrows, ncols, stream_ptr()),
          nbytes=nrows * (ncols + 4 * ld_dst))
+
+
+ONEHOT_LDS_MAX = 150 << 10
+
+
+def onehot_fits(F: int, ld: int) -> bool:
+    """The transposed weight of a feature layer fits the LDS of a CU (see jtvae_onehot_linear)."""
+    return F * ld * 4 + 128 * ((F + 3) // 4) * 4 <= ONEHOT_LDS_MAX and ld // 4 <= 256
+
+
+def onehot_linear(feats, n_rows, F, Wt, ldw, bias, out, ld, H):
+    _run("onehot_linear", lib.jtvae_onehot_linear, (feats, n_rows, F, Wt, ldw, bias, out, ld, H, stream_ptr()),
+         nbytes=n_rows * (F + 4 * H) + 4 * F * H)
+
+
+def onehot_linear_bwd(feats, n_rows, F, dOut, ld, H, dW, lddw, accumulate, device):
+    nbytes = lib.jtvae_onehot_linear_bwd_workspace_bytes(n_rows, F, ld)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    _run("onehot_linear_bwd", lib.jtvae_onehot_linear_bwd,
+         (feats, n_rows, F, dOut, ld, H, dW, lddw, int(accumulate), ws.data_ptr(), nbytes, stream_ptr()),
+         nbytes=n_rows * (F + 4 * H) + 4 * F * H)
 
 
 def csr_gather_sum(out, src0, n_src0, src1, rowptr, col, n_rows, H, ld, relu_mask=None, accumulate=False,

@@ -71,19 +71,6 @@ def _attach(t: torch.Tensor, tag, value) -> None:
     graphprep.cached_prep(t, tag, lambda: value)
 
 
-def _widen(feat_u8: torch.Tensor, device) -> torch.Tensor:
-    n, f = feat_u8.shape
-    fp = (f + 3) // 4 * 4
-    out = graphprep._new_device_tensor(torch.empty((n, fp), dtype=torch.float32, device=device))
-    if n:
-        if device.type == "cuda":
-            K.widen_u8_rows(feat_u8.data_ptr(), out.data_ptr(), fp, n, f)
-        else:  # CPU stand-in for tests of the index side
-            out.zero_()
-            out[:, :f] = feat_u8.float()
-    return out
-
-
 def graph_prep(gs: flat.GraphSet, ids, device, mess=None, max_nb: int = flat.MPN_MAX_NB, train: bool = True,
                threads: int = None) -> GraphMPNPrep:
     """GraphMPNPrep of the selected graphs (``mess``: the batch's tree messages for candidate graphs)."""
@@ -98,10 +85,9 @@ def graph_prep(gs: flat.GraphSet, ids, device, mess=None, max_nb: int = flat.MPN
         return DeviceCSR(d[rp], d[col][:max(nnz, 1)], n_rows, nnz)
 
     n_src = n_tree + rows
-    with torch.cuda.device(device) if device.type == "cuda" else _Null():
-        fatoms, fbonds = _widen(d["fatoms"], device), _widen(d["fbonds"], device)
-    return GraphMPNPrep(
-        fatoms=fatoms, fbonds=fbonds, atom_fdim=o["atom_fdim"], bond_in_fdim=o["bond_in_fdim"],
+    return GraphMPNPrep(  # the feature rows stay bytes; a dense product that wants floats widens them on demand
+        fatoms=None, fbonds=None, fatoms_u8=d["fatoms"], fbonds_u8=d["fbonds"],
+        atom_fdim=o["atom_fdim"], bond_in_fdim=o["bond_in_fdim"],
         n_atoms=na, n_bonds=rows, n_tree=n_tree,
         bcsr=csr("b_rowptr", "b_col", rows, o["b_nnz"]),
         bcsr_t=csr("bt_rowptr", "bt_col", n_src, o["b_nnz"]) if train else None,
@@ -109,14 +95,6 @@ def graph_prep(gs: flat.GraphSet, ids, device, mess=None, max_nb: int = flat.MPN
         acsr_t=csr("at_rowptr", "at_col", n_src, o["a_nnz"]) if train else None,
         seg=d["seg"], seg_of=d["seg_of"], n_seg=n, b_tree_nnz=o["b_tree_nnz"], a_tree_nnz=o["a_tree_nnz"],
         host=None)
-
-
-class _Null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
 
 
 def tree_prep(ts: flat.TreeSet, ids, device, vocab_size: int, depth: int, train: bool = True,

@@ -221,13 +221,29 @@ def upload_csr(rowptr: np.ndarray, col: np.ndarray, device) -> DeviceCSR:
     return DeviceCSR(_dev_i32(rowptr, device), col_t, int(rowptr.shape[0] - 1), int(col.shape[0]))
 
 
-def _upload_features(x: np.ndarray, device) -> torch.Tensor:
-    """[n, f] float32 -> device [n, round4(f)] with zero padding columns.
+def _widen_features(packed: torch.Tensor) -> torch.Tensor:
+    """[n, f] bytes on the device -> [n, round4(f)] float rows with zero padding columns (one kernel)."""
+    n, f = packed.shape
+    fp = (f + 3) // 4 * 4
+    out = _new_device_tensor(torch.empty((n, fp), dtype=torch.float32, device=packed.device))
+    if n:
+        if packed.is_cuda:
+            with torch.cuda.device(packed.device):
+                K.widen_u8_rows(packed.data_ptr(), out.data_ptr(), fp, n, f)
+        else:  # CPU stand-in for tests of the index side
+            out.zero_()
+            out[:, :f] = packed.float()
+    return out
+
+
+def _upload_features(x: np.ndarray, device):
+    """[n, f] float32 feature rows -> (float rows [n, round4(f)] or None, byte rows [n, f] or None) on the device.
 
     The rows are one-hot blocks (fast_jtnn/mpn.py:18-31).  When every value is a whole number in [0, 255] -
     checked in the pass that converts them - they cross the link as bytes in pinned memory, a quarter of the
-    float size, and one kernel widens them into the padded rows: the same bits as shipping the floats.  Any
-    other content goes as floats and is padded on the device."""
+    float size, and stay bytes: the feature layers read them as they are (``jtvae_onehot_linear``), and a consumer
+    that wants float rows widens them on the device (``GraphMPNPrep.float_rows``: the same bits as shipping the
+    floats).  Any other content goes as floats and is padded on the device."""
     n, f = x.shape
     fp = (f + 3) // 4 * 4
     x = np.ascontiguousarray(x)
@@ -235,16 +251,13 @@ def _upload_features(x: np.ndarray, device) -> torch.Tensor:
     if n and device.type == "cuda":
         stage = torch.empty((n, f), dtype=torch.uint8, pin_memory=True)
         if K.prep_features_to_u8(x, stage.numpy()):
-            packed = stage.to(device, non_blocking=True)  # read by the next launch on this stream only
-            out = _new_device_tensor(torch.empty((n, fp), dtype=torch.float32, device=device))
-            K.widen_u8_rows(packed.data_ptr(), out.data_ptr(), fp, n, f)
-            return out
+            return None, _new_device_tensor(stage.to(device, non_blocking=True))
     src = _new_device_tensor(torch.from_numpy(x).to(device, non_blocking=True))
     if fp == f:
-        return src
+        return src, None
     out = _new_device_tensor(torch.zeros((n, fp), dtype=torch.float32, device=device))
     out[:, :f] = src
-    return out
+    return out, None
 
 
 def scope_arrays(scope: Sequence[Tuple[int, int]], n_rows: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -270,8 +283,8 @@ class GraphMPNPrep:
     rows first (0 for the plain MPN), then the ``n_bonds`` bond-message rows.
     """
 
-    fatoms: torch.Tensor  # [NA, round4(atom_fdim)]
-    fbonds: torch.Tensor  # [NB, round4(atom_fdim + bond_fdim)]
+    fatoms: Optional[torch.Tensor]  # [NA, round4(atom_fdim)] float rows, or None while only the bytes exist
+    fbonds: Optional[torch.Tensor]  # [NB, round4(atom_fdim + bond_fdim)]
     atom_fdim: int
     bond_in_fdim: int
     n_atoms: int
@@ -287,12 +300,22 @@ class GraphMPNPrep:
     b_tree_nnz: int = 0  # bgraph / agraph entries that point at tree-message rows
     a_tree_nnz: int = 0
     host: dict = None  # CSR arrays kept for the transposes when they were not built (inference)
+    fatoms_u8: Optional[torch.Tensor] = None  # [NA, atom_fdim] bytes when every feature is a whole number 0..255
+    fbonds_u8: Optional[torch.Tensor] = None  # [NB, atom_fdim + bond_fdim]
+
+    def float_rows(self, which: str) -> torch.Tensor:
+        """``fatoms`` / ``fbonds`` as padded float rows (for the dense products), widened from the bytes on first use."""
+        rows = getattr(self, which)
+        if rows is None:
+            rows = _widen_features(getattr(self, which + "_u8"))
+            setattr(self, which, rows)
+        return rows
 
     def ensure_transposes(self):
         """The transposed adjacency is only read by the backward pass; a holder prepared for inference gets it
         on its first use under gradient mode."""
         if self.bcsr_t is None:
-            h, dev = self.host, self.fatoms.device
+            h, dev = self.host, self.seg.device
             n_src = self.n_tree + self.n_bonds
             with packed_uploads(dev):
                 self.bcsr_t = upload_csr(*transpose_csr(h["b_rp"], h["b_col"], n_src), dev)
@@ -317,9 +340,10 @@ def _prepare_mpn(holder, device, n_tree: int = 0, train: bool = True) -> GraphMP
     b_rp, b_col = padded_to_csr(bg, n_src)
     a_rp, a_col = padded_to_csr(ag, n_src)
     seg, seg_of = scope_arrays(scope, na)
+    fa_f, fa_u = _upload_features(fa, device)
+    fb_f, fb_u = _upload_features(fb, device)
     return GraphMPNPrep(
-        fatoms=_upload_features(fa, device),
-        fbonds=_upload_features(fb, device),
+        fatoms=fa_f, fbonds=fb_f, fatoms_u8=fa_u, fbonds_u8=fb_u,
         atom_fdim=fa.shape[1], bond_in_fdim=fb.shape[1],
         n_atoms=na, n_bonds=nb, n_tree=n_tree,
         bcsr=upload_csr(b_rp, b_col, device),

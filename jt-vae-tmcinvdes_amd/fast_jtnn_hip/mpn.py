@@ -35,6 +35,10 @@ BOND_FDIM = MPN_BOND_FDIM  # 12, fast_jtnn/mpn.py:36
 MAX_NB = MPN_MAX_NB  # 6,  fast_jtnn/mpn.py:37
 
 
+# The feature layers (W_i on the bond rows, the atom columns of W_o) run as one-hot row kernels when the holder's
+# feature rows are bytes and the transposed weight fits in LDS; False sends them through the dense products.
+ONEHOT = True
+
 _PACK_CACHE = OrderedDict()  # layout key -> (weights, their versions, packed buffers)
 _PACK_CACHE_MAX = 16
 
@@ -148,7 +152,10 @@ class _GraphMPNFunction(torch.autograd.Function):
         # grad mode is off inside forward(): the caller's mode comes in as an argument
         train = grad_on and any(ctx.needs_input_grad)
 
-        Wi, Wh, Woa, Woh = pack_weights([(W_i, 0, fb_dim, False), (W_h, 0, H, False), (W_o_w, 0, fa_dim, False),
+        oh_b = ONEHOT and P.fbonds_u8 is not None and K.onehot_fits(fb_dim, ld)
+        oh_a = ONEHOT and P.fatoms_u8 is not None and K.onehot_fits(fa_dim, ld)
+        # one-hot layers take the transposed weight block ([features, ld]: a table of rows to add up)
+        Wi, Wh, Woa, Woh = pack_weights([(W_i, 0, fb_dim, oh_b), (W_h, 0, H, False), (W_o_w, 0, fa_dim, oh_a),
                                          (W_o_w, fa_dim, H, False)])
         tree = None
         if TM:
@@ -167,8 +174,12 @@ class _GraphMPNFunction(torch.autograd.Function):
         binput = K.rows(NB, ld, dev)
         # binput = W_i fbonds; message 0 = relu(binput) is never stored: its readers take the ReLU themselves
         # and the backward mask (message > 0) is binput > 0                                    (mpn.py:87-88)
-        K.gemm_nt(P.fbonds.data_ptr(), P.fbonds.stride(0), Wi.data_ptr(), Wi.stride(0), binput.data_ptr(), ld,
-                  NB, H, fb_dim)
+        if oh_b:
+            K.onehot_linear(P.fbonds_u8.data_ptr(), NB, fb_dim, Wi.data_ptr(), Wi.stride(0), None, binput.data_ptr(), ld, H)
+        else:
+            fbonds = P.float_rows("fbonds")
+            K.gemm_nt(fbonds.data_ptr(), fbonds.stride(0), Wi.data_ptr(), Wi.stride(0), binput.data_ptr(), ld,
+                      NB, H, fb_dim)
         msgs = [binput]
         neis = []
         for _ in range(depth - 1):  # mpn.py:90-94
@@ -185,8 +196,13 @@ class _GraphMPNFunction(torch.autograd.Function):
         anei = K.rows(NA, ld, dev)  # mpn.py:96-99
         gather(anei, msgs[-1], P.acsr, NA, msgs[-1] is binput)
         ah = K.rows(NA, ld, dev)
-        K.gemm_nt(P.fatoms.data_ptr(), P.fatoms.stride(0), Woa.data_ptr(), Woa.stride(0), ah.data_ptr(), ld,
-                  NA, H, fa_dim, bias=W_o_b.detach().data_ptr())
+        if oh_a:
+            K.onehot_linear(P.fatoms_u8.data_ptr(), NA, fa_dim, Woa.data_ptr(), Woa.stride(0),
+                            W_o_b.detach().data_ptr(), ah.data_ptr(), ld, H)
+        else:
+            fatoms = P.float_rows("fatoms")
+            K.gemm_nt(fatoms.data_ptr(), fatoms.stride(0), Woa.data_ptr(), Woa.stride(0), ah.data_ptr(), ld,
+                      NA, H, fa_dim, bias=W_o_b.detach().data_ptr())
         K.gemm_nt(anei.data_ptr(), ld, Woh.data_ptr(), ld, ah.data_ptr(), ld, NA, H, H,
                   add=ah.data_ptr(), ld_add=ld, act=K.ACT_RELU)
         out = K.rows(P.n_seg, ld, dev)  # mpn.py:102-107
@@ -198,6 +214,7 @@ class _GraphMPNFunction(torch.autograd.Function):
             ctx.saved = (msgs, neis, anei, ah, W_h, W_o_w)
             ctx.W_i_shape, ctx.W_o_shape = tuple(W_i.shape), tuple(W_o_w.shape)
             ctx.has_tree = bool(TM)
+            ctx.onehot = (oh_a, oh_b)
         return dense_view(out, H)
 
     @staticmethod
@@ -221,8 +238,14 @@ class _GraphMPNFunction(torch.autograd.Function):
         K.segment_mean_bwd(dpre_o.data_ptr(), dout_p.data_ptr(), ah.data_ptr(), P.seg.data_ptr(),
                            P.seg_of.data_ptr(), NA, H, ld, n_seg=P.n_seg)
         w_in = ctx.W_o_shape[1]
-        K.gemm_tn(dpre_o.data_ptr(), ld, P.fatoms.data_ptr(), P.fatoms.stride(0), dW_o.data_ptr(), w_in,
-                  NA, H, fa_dim, False, dev)
+        oh_a, oh_b = ctx.onehot
+        if oh_a:
+            K.onehot_linear_bwd(P.fatoms_u8.data_ptr(), NA, fa_dim, dpre_o.data_ptr(), ld, H, dW_o.data_ptr(), w_in,
+                                False, dev)
+        else:
+            fatoms = P.float_rows("fatoms")
+            K.gemm_tn(dpre_o.data_ptr(), ld, fatoms.data_ptr(), fatoms.stride(0), dW_o.data_ptr(), w_in,
+                      NA, H, fa_dim, False, dev)
         K.gemm_tn(dpre_o.data_ptr(), ld, anei.data_ptr(), ld, K.ptr(dW_o, fa_dim), w_in, NA, H, H, False, dev,
                   dbias=db_o.data_ptr())
         danei = K.rows(NA, ld, dev)
@@ -250,8 +273,13 @@ class _GraphMPNFunction(torch.autograd.Function):
             dpre = gather_t(dnei, P.bcsr_t, P.b_tree_nnz, msgs[i - 1], dbinput, False)
         if depth == 1:
             dW_h.zero_()
-        K.gemm_tn(dbinput.data_ptr(), ld, P.fbonds.data_ptr(), P.fbonds.stride(0), dW_i.data_ptr(),
-                  ctx.W_i_shape[1], NB, H, fb_dim, False, dev)
+        if oh_b:
+            K.onehot_linear_bwd(P.fbonds_u8.data_ptr(), NB, fb_dim, dbinput.data_ptr(), ld, H, dW_i.data_ptr(),
+                                ctx.W_i_shape[1], False, dev)
+        else:
+            fbonds = P.float_rows("fbonds")
+            K.gemm_tn(dbinput.data_ptr(), ld, fbonds.data_ptr(), fbonds.stride(0), dW_i.data_ptr(),
+                      ctx.W_i_shape[1], NB, H, fb_dim, False, dev)
         dtree_out = None
         if TM and ctx.needs_input_grad[4]:
             dtree_out = dense_view(dtree, H)

@@ -174,7 +174,8 @@ def test_flat_route_prepares_what_the_table_route_prepares():
     got = flatprep.graph_prep(shard.mols, None, dev, train=True, threads=2)
     for f in ("n_atoms", "n_bonds", "n_tree", "n_seg", "atom_fdim", "bond_in_fdim", "a_tree_nnz", "b_tree_nnz"):
         assert getattr(want, f) == getattr(got, f), f
-    assert torch.equal(want.fatoms, got.fatoms) and torch.equal(want.fbonds, got.fbonds)
+    assert torch.equal(want.float_rows("fatoms"), got.float_rows("fatoms"))
+    assert torch.equal(want.float_rows("fbonds"), got.float_rows("fbonds"))
     for f in ("acsr", "bcsr", "acsr_t", "bcsr_t"):
         same_csr(getattr(want, f), getattr(got, f))
     assert torch.equal(want.seg.cpu(), got.seg.cpu()) and torch.equal(want.seg_of.cpu(), got.seg_of.cpu())
@@ -200,7 +201,7 @@ def test_flat_route_prepares_what_the_table_route_prepares():
         assert getattr(wc, f) == getattr(gc, f), f
     for f in ("acsr", "bcsr", "acsr_t", "bcsr_t"):
         same_csr(getattr(wc, f), getattr(gc, f))
-    assert torch.equal(wc.fbonds, gc.fbonds)
+    assert torch.equal(wc.float_rows("fbonds"), gc.float_rows("fbonds"))
 
 
 def test_deep_tree_takes_the_table_route():

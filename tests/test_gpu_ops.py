@@ -641,3 +641,45 @@ def test_level_sweeps_reject_bad_arguments_and_accept_an_empty_schedule(K):
     b = K.TreeBwd(H=450, ld=452, n_levels=2, T=20)
     assert K.lib.jtvae_tree_gru_backward(C.byref(b), K.stream_ptr()) == K.E_NULL
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n_rows,F,H", [(1, 51, 450), (777, 44, 450), (40000, 39, 450), (300, 12, 96)])
+def test_onehot_linear_forward_and_weight_gradient(n_rows, F, H):
+    """jtvae_onehot_linear / _bwd against fp64 numpy on byte rows with a few set entries (and the odd entry > 1),
+    and bitwise against themselves on a second run (fixed summation order)."""
+    from fast_jtnn_hip import _capi as K
+
+    rs = np.random.RandomState(n_rows + F)
+    ld = K.round_ld(H)
+    feats = (rs.rand(n_rows, F) < 0.15).astype(np.uint8)
+    feats[rs.randint(0, n_rows, size=3), rs.randint(0, F, size=3)] = 3
+    W = rs.standard_normal((H, F)).astype(np.float32)
+    bias = rs.standard_normal(H).astype(np.float32)
+    Wt = torch.zeros((F, ld), dtype=torch.float32, device="cuda")
+    Wt[:, :H] = torch.from_numpy(W.T.copy()).cuda()
+    f_dev = torch.from_numpy(feats).cuda()
+    b_dev = torch.from_numpy(bias).cuda()
+    outs = []
+    for _ in range(2):
+        out = torch.full((n_rows, ld), float("nan"), device="cuda")
+        K.onehot_linear(f_dev.data_ptr(), n_rows, F, Wt.data_ptr(), ld, b_dev.data_ptr(), out.data_ptr(), ld, H)
+        outs.append(out.cpu().numpy())
+    want = feats.astype(np.float64) @ W.T.astype(np.float64) + bias
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0][:, :H] - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
+    assert not outs[0][:, H:].any()  # padding columns written as zero
+    # weight gradient, fresh and accumulated
+    d = torch.zeros((n_rows, ld), device="cuda")
+    d[:, :H] = torch.from_numpy(rs.standard_normal((n_rows, H)).astype(np.float32)).cuda()
+    want_dw = d.cpu().numpy()[:, :H].astype(np.float64).T @ feats.astype(np.float64)
+    init = torch.from_numpy(rs.standard_normal((H, F)).astype(np.float32)).cuda()
+    grads = []
+    for acc in (False, False, True):
+        dW = init.clone()
+        K.onehot_linear_bwd(f_dev.data_ptr(), n_rows, F, d.data_ptr(), ld, H, dW.data_ptr(), F, acc, "cuda")
+        grads.append(dW.cpu().numpy())
+    assert np.array_equal(grads[0], grads[1])
+    scale = max(np.abs(want_dw).max(), 1.0)
+    assert np.abs(grads[0] - want_dw).max() <= 2e-5 * scale
+    assert np.abs(grads[2] - (want_dw + init.cpu().numpy())).max() <= 2e-5 * scale
+    assert K.lib.jtvae_onehot_linear(16, 4, 400, 16, 452, None, 16, 452, 450, None) == K.E_WORKSPACE  # table too big
