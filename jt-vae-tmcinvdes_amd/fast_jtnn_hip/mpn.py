@@ -21,6 +21,7 @@ gathers read from ``[tree messages ; bond messages]``.
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import torch
@@ -35,9 +36,12 @@ BOND_FDIM = MPN_BOND_FDIM  # 12, fast_jtnn/mpn.py:36
 MAX_NB = MPN_MAX_NB  # 6,  fast_jtnn/mpn.py:37
 
 
-# The feature layers (W_i on the bond rows, the atom columns of W_o) run as one-hot row kernels when the holder's
-# feature rows are bytes and the transposed weight fits in LDS; False sends them through the dense products.
-ONEHOT = True
+# True: the feature layers (W_i on the bond rows, the atom columns of W_o) run as one-hot row kernels
+# (jtvae_onehot_linear) when the holder's feature rows are bytes and the transposed weight fits in LDS.  Off by
+# default: measured on MI355X they do not beat the dense K = 39..51 products (both sit near 30 % of the HBM rate -
+# the row kernels bound by LDS reads of the weight table, the products by MFMA work on padding), and the gradient
+# form is slower.  JTVAE_ONEHOT=1 switches them on.
+ONEHOT = os.environ.get("JTVAE_ONEHOT", "0") == "1"
 
 _PACK_CACHE = OrderedDict()  # layout key -> (weights, their versions, packed buffers)
 _PACK_CACHE_MAX = 16

@@ -74,3 +74,35 @@ def test_packed_weights_follow_the_parameters():
         assert torch.equal(m(*holder), back)
         m = m.cpu().cuda()  # new storage, same Parameter objects
         assert torch.equal(m(*holder), back)
+
+
+def test_onehot_feature_layers_agree_with_the_dense_products():
+    """mpn.ONEHOT routes W_i / the atom columns of W_o through the one-hot row kernels: same results as the
+    dense products up to fp32 summation order, forward and backward, for MPN and JTMPN."""
+    import fast_jtnn_hip.mpn as mpn_mod
+    from fast_jtnn_hip import JTNNVAE, synthetic
+    from fast_jtnn_hip import tensorize as T
+
+    V, B = 31, 12
+    trees = synthetic.make_batch(5, B, vocab_size=V, mean_atoms=22.0, with_cands=True)
+    m = JTNNVAE(synthetic.FakeVocab(V), 450, 56, 20, 3, decoder=False)
+    synthetic.fill_params(list(m.named_parameters()), 6, 0.05)
+    m = m.cuda()
+    out = []
+    old = mpn_mod.ONEHOT
+    try:
+        for flag in (False, True):
+            mpn_mod.ONEHOT = flag
+            _, jt, mp, (cj, bi) = T.tensorize(trees, assm=True)  # fresh holders: nothing cached from the other route
+            m.zero_grad(set_to_none=True)
+            tv, ms, mv = m.encode(jt, mp)
+            cv = m.jtmpn(*cj, ms)
+            (mv.sum() + (cv * cv).sum()).backward()
+            out.append((mv.detach().cpu().numpy(), cv.detach().cpu().numpy(),
+                        {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        mpn_mod.ONEHOT = old
+    (mv0, cv0, g0), (mv1, cv1, g1) = out
+    assert rel_err(mv1, mv0) < 1e-5 and rel_err(cv1, cv0) < 1e-5
+    for k in ("mpn.W_i.weight", "mpn.W_o.weight", "jtmpn.W_i.weight", "jtmpn.W_o.weight", "mpn.W_h.weight"):
+        assert np.linalg.norm(g1[k] - g0[k]) <= 2e-5 * np.linalg.norm(g0[k]), k

@@ -190,7 +190,9 @@ def test_byte_feature_rows_widen_to_the_floats_they_came_from(K):
     rs = np.random.RandomState(3)
     x = (rs.rand(1237, 39) < 0.1).astype(np.float32)
     x[5, 7] = 255.0
-    got = G._upload_features(x, "cuda")
+    rows, packed = G._upload_features(x, "cuda")
+    assert rows is None and packed.dtype == torch.uint8 and np.array_equal(packed.cpu().numpy(), x.astype(np.uint8))
+    got = G._widen_features(packed)
     torch.cuda.synchronize()
     assert got.shape == (1237, 40) and np.array_equal(got[:, :39].cpu().numpy(), x)
     assert float(got[:, 39].abs().max()) == 0.0
@@ -199,7 +201,8 @@ def test_byte_feature_rows_widen_to_the_floats_they_came_from(K):
     y = x.copy()
     y[1000, 38] = 0.5
     assert not K.prep_features_to_u8(y, stage)
-    got = G._upload_features(y, "cuda")
+    got, packed = G._upload_features(y, "cuda")
+    assert packed is None
     assert np.array_equal(got[:, :39].cpu().numpy(), y) and float(got[:, 39].abs().max()) == 0.0
     assert K.lib.jtvae_widen_u8_rows(None, got.data_ptr(), 40, 5, 39, None) == K.E_NULL
     assert K.lib.jtvae_widen_u8_rows(got.data_ptr(), got.data_ptr(), 36, 5, 39, None) == K.E_SHAPE
