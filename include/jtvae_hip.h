@@ -132,7 +132,9 @@ int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const floa
  * ends (jtvae_gemm_tn_static_max_bytes() = 64 MiB: enough for every N, K <= 450 product at any M).
  * It has no counterpart in the reference; it is for callers that cannot allocate (code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same slab plan as
- * jtvae_gemm_tn, so results are bit-identical to it.  A product whose partials need more than the
+ * jtvae_gemm_tn - results are bit-identical to it - while that plan's partials fit the array (up to ~0.7 M
+ * rows for N = K = 450); longer products keep one round of longer slabs here, jtvae_gemm_tn runs several rounds
+ * of 8192-row slabs, and the two agree to fp32 rounding.  A product whose partials need more than the
  * array holds is rejected with JTVAE_E_WORKSPACE before any launch.  All calls on one GPU share the
  * array: calls that overlap on one GPU (two streams, two threads) race; issue them on one stream.
  * The array used is the one of the GPU that owns `stream` (of the current device for the NULL stream); the

@@ -999,7 +999,13 @@ inline int launch_status() {
 struct TnPlan {
   int tiles_n, tiles_k, splits, rows_per_split, ldp, nacc;
 };
-inline TnPlan tn_plan(int M, int N, int K, int ones_col) {
+// Slab length above which the product runs in several rounds of the resident grid instead of one round of longer
+// slabs (0 = never): the tiles of a slab share its rows through one L2, and over thousands of K steps they drift
+// apart until every tile fetches the rows from HBM for itself; 8192-row slabs keep them in step (measured on
+// M = 5.3 M rows: 98 -> 102 TFLOP/s, and the shorter fp32 chains lose fewer digits).
+constexpr int TN_MAX_SLAB_ROWS = 8192;
+
+inline TnPlan tn_plan(int M, int N, int K, int ones_col, int max_slab = TN_MAX_SLAB_ROWS) {
   TnPlan p;
   const int kk = K + ones_col;
   if (kk <= 64) {
@@ -1025,6 +1031,10 @@ inline TnPlan tn_plan(int M, int N, int K, int ones_col) {
   int cap = resident / tiles;
   int s = want < cap ? want : cap;
   if (s < 1) s = 1;
+  if (max_slab > 0 && (M + s - 1) / s > max_slab) {
+    int rounds = ((M + max_slab - 1) / max_slab + cap - 1) / cap;
+    s = rounds * cap;  // whole rounds: a few blocks more than the chip holds would run alone behind a full round
+  }
   int rows = (M + s - 1) / s;
   rows = (rows + TN_BM - 1) / TN_BM * TN_BM;
   if (rows < TN_BM) rows = TN_BM;
@@ -1147,6 +1157,8 @@ int gemm_tn_run(const float* X, int32_t ldx, const int32_t* x_rows, const float*
   if (!X || !Y || !dW || !workspace) return JTVAE_E_NULL;
   const int ones_col = dbias ? 1 : 0;
   TnPlan p = tn_plan(M, N, K, ones_col);
+  if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float))
+    p = tn_plan(M, N, K, ones_col, 0);  // a smaller workspace (the static array) takes one round of longer slabs
   if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float)) return JTVAE_E_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(workspace) & 15) return JTVAE_E_ALIGN;
   TnArgs a;
@@ -1361,8 +1373,13 @@ int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, con
                          const int32_t* y_rows, float* dW, int32_t lddw, float* dbias, int32_t M, int32_t N,
                          int32_t K, int32_t accumulate, void* stream) {
   if (M < 0 || N <= 0 || K <= 0) return JTVAE_E_SHAPE;
-  // same slab plan as jtvae_gemm_tn, so the result is bit-identical to it
-  if (jtvae_gemm_tn_workspace_bytes(M, N, K) > TN_SCRATCH_BYTES) return JTVAE_E_WORKSPACE;
+  // same slab plan as jtvae_gemm_tn whenever that plan's partials fit the array (bit-identical results then);
+  // a product of more than ~0.7 M rows keeps one round of longer slabs here
+  {
+    TnPlan p0 = tn_plan(M, N, K, 0, 0), p1 = tn_plan(M, N, K, 1, 0);
+    const size_t need = (size_t)(p0.splits > p1.splits ? p0.splits : p1.splits) * N * p0.ldp * sizeof(float);
+    if (need > TN_SCRATCH_BYTES) return JTVAE_E_WORKSPACE;
+  }
   void* ws = nullptr;
   const int rc = tn_scratch_for_stream((hipStream_t)stream, &ws);
   if (rc != 0) return rc;

@@ -209,6 +209,42 @@ def shard_from_trees(tree_batch: Sequence, with_cands: bool = False) -> FlatShar
     return FlatShard(ts, graph_set_from_objects([t.mol for t in tree_batch]), cs)
 
 
+# ---- flat form on disk ------------------------------------------------------------------------------
+
+
+def save_shard(path: str, shard: FlatShard, props: Optional[np.ndarray] = None) -> None:
+    """One ``.npz`` of plain arrays (no pickled objects): what the reference keeps as pickled MolTree lists
+    (fast_molvae/preprocess.py:39-57).  ``props``: the property table of the conditional model, one row per
+    molecule (fast_jtnn/datautils_prop.py:161-175)."""
+    a = {}
+    for prefix, obj, names in (("t_", shard.trees, ("node_ptr", "wid", "nbr_ptr", "nbr", "cand_ptr", "label")),
+                               ("m_", shard.mols, ("atom_ptr", "bond_ptr", "atom_feats", "bonds", "bond_feats")),
+                               ("c_", shard.cands, ("atom_ptr", "bond_ptr", "atom_feats", "bonds", "bond_feats",
+                                                    "atom_nid"))):
+        if obj is None:
+            continue
+        for n in names:
+            v = getattr(obj, n)
+            if v is not None:
+                a[prefix + n] = v
+    if props is not None:
+        a["props"] = np.asarray(props, dtype=np.float32)
+    np.savez(path, **a)
+
+
+def load_shard(path: str):
+    """(FlatShard, props or None) of a file written by ``save_shard``; nothing in the file is executed."""
+    z = np.load(path, allow_pickle=False)
+    g = lambda k: z[k] if k in z.files else None  # noqa: E731
+    trees = TreeSet(z["t_node_ptr"], z["t_wid"], z["t_nbr_ptr"], z["t_nbr"], g("t_cand_ptr"), g("t_label"))
+    mols = GraphSet(z["m_atom_ptr"], z["m_bond_ptr"], z["m_atom_feats"], z["m_bonds"], z["m_bond_feats"])
+    cands = None
+    if "c_atom_ptr" in z.files:
+        cands = GraphSet(z["c_atom_ptr"], z["c_bond_ptr"], z["c_atom_feats"], z["c_bonds"], z["c_bond_feats"],
+                         z["c_atom_nid"])
+    return FlatShard(trees, mols, cands), g("props")
+
+
 # ---- the mess_dict of JTNNEncoder.tensorize, backed by arrays --------------------------------------
 
 
@@ -399,5 +435,5 @@ def candidate_mess(src, dst, n_nodes, node_base) -> _Mess:
 
 
 __all__ = ["GraphSet", "TreeSet", "FlatShard", "MessDict", "graph_set_from_objects", "tree_set_from_nodes",
-           "shard_from_trees", "graph_tables", "graph_csr", "tree_tables", "tree_csr", "select_candidates",
+           "shard_from_trees", "save_shard", "load_shard", "graph_tables", "graph_csr", "tree_tables", "tree_csr", "select_candidates",
            "candidate_mess", "mess_arrays", "host_threads", "JTMPN_MAX_NB", "MPN_MAX_NB"]

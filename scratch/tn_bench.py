@@ -10,7 +10,7 @@ import torch
 from fast_jtnn_hip import _capi as K
 
 TN_SHAPES = [(385, 450, 450, 1), (1024, 450, 450, 1), (10310, 450, 450, 1), (17820, 450, 450, 1), (25000, 450, 450, 1), (40898, 450, 450, 1), (84000, 450, 450, 1), (84000, 450, 50, 1), (40000, 450, 485, 1),
-             (13000, 450, 900, 1), (330000, 450, 450, 1), (1320000, 450, 450, 0)]
+             (13000, 450, 900, 1), (330000, 450, 450, 1), (1320000, 450, 450, 0), (5300000, 450, 450, 0)]
 NT_SHAPES = [(25000, 450, 450), (84000, 450, 450), (84000, 450, 50), (330000, 450, 450), (1320000, 450, 450),
              (2000, 450, 450), (6000, 450, 450)]
 
@@ -38,7 +38,10 @@ def main():
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(0)
     if what == "tn":
+        only = int(os.environ.get("TN_MIN_M", "0"))
         for M, N, Kk, bias in TN_SHAPES:
+            if M < only:
+                continue
             # rotate over enough operand copies that no call finds its rows in the 256 MB memory-side cache
             copies = max(1, min(8, int(700e6 // (4.0 * M * (ld4(N) + ld4(Kk)))) + 1))
             Xs = [torch.randn(M, ld4(N), generator=g).to(dev) for _ in range(copies)]

@@ -220,3 +220,17 @@ def test_deep_tree_takes_the_table_route():
     holder, _ = flatprep._tree_holder(shard.trees, None, torch.device("cpu"), 7, 20, False, False, None)
     want, _ = R.jtenc_tensorize([tree])
     assert all(torch.equal(x, y) for x, y in zip(holder[:4], want[:4])) and holder[4] == want[4]
+
+
+def test_shard_file_round_trip(tmp_path):
+    trees = _batch(61, 7, 14.0)
+    shard = flat.shard_from_trees(trees, with_cands=True)
+    props = np.arange(14, dtype=np.float32).reshape(7, 2)
+    path = str(tmp_path / "set.npz")
+    flat.save_shard(path, shard, props)
+    back, p2 = flat.load_shard(path)
+    assert np.array_equal(p2, props) and back.n == 7
+    for a, b in ((shard.trees, back.trees), (shard.mols, back.mols), (shard.cands, back.cands)):
+        for k, v in vars(a).items():
+            assert np.array_equal(v, getattr(b, k)), k
+    assert all(np.array_equal(x, y) for x, y in zip(flat.graph_tables(shard.mols), flat.graph_tables(back.mols)))

@@ -323,3 +323,28 @@ def test_training_cli_writes_checkpoints_the_oracle_model_loads(tmp_path):
         assert tuple(state[k].shape) == tuple(v.shape), k
         assert torch.isfinite(state[k]).all(), k
     ora.load_state_dict(state)
+
+
+def test_training_cli_from_a_flat_data_set(tmp_path):
+    """train.py --train flat:<file>: the conditional loop (fast_molopt/vae_train_prop.py:116-150) on a data set stored
+    as flat arrays, batches tensorized natively in the prefetch threads."""
+    import os
+    import subprocess
+    import sys
+
+    from fast_jtnn_hip import flat, synthetic
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    trees = synthetic.make_batch(4, 160, vocab_size=45, mean_atoms=16.0, with_cands=True)
+    rs = np.random.RandomState(0)
+    props = np.stack([rs.standard_normal(160), rs.standard_normal(160), rs.randint(0, 2, 160), rs.randint(0, 3, 160)],
+                     axis=1).astype(np.float32)
+    data = str(tmp_path / "train.npz")
+    flat.save_shard(data, flat.shard_from_trees(trees, with_cands=True), props)
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, "train.py"), "--train", "flat:" + data, "--vocab", "45", "--save_dir",
+         str(tmp_path / "out"), "--batch_size", "64", "--epoch", "2", "--print_iter", "1", "--conditional",
+         "--train_mode", "denticity", "isomer"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("Loss:") == 4 and "prop_loss" in out.stdout and "isomer_loss" in out.stdout
+    assert "model.epoch-4" in os.listdir(tmp_path / "out")

@@ -7,9 +7,10 @@ process per GPU, gradients joined by one RCCL all-reduce per step.
     python train.py --train synthetic:20000 --vocab 385 --save_dir out --conditional --train_mode denticity isomer --gpus 8
 
 ``--batch_size`` is the GLOBAL batch; every rank takes an equal share of each batch by molecule and builds
-the holders of its own share.  ``--train synthetic:N[:seed]`` draws N abstract molecules from the in-package
-generator (turning SMILES into graphs needs RDKit and stays with the caller: ``fast_jtnn_hip.tensorize``
-accepts any object with the same fields).  ``--vocab`` is a vocabulary file (one entry per line; only its
+the holders of its own share with the native tensorizers.  ``--train synthetic:N[:seed]`` draws N abstract
+molecules from the in-package generator; ``--train flat:<file.npz>`` reads a data set in flat form
+(``fast_jtnn_hip.flat.save_shard``: atoms, bonds, feature bytes, tree neighbour lists, candidates - turning SMILES
+into those arrays needs RDKit and stays with the caller).  ``--vocab`` is a vocabulary file (one entry per line; only its
 length is used for synthetic data) or an integer.
 """
 import argparse
@@ -61,32 +62,37 @@ def vocab_size(spec: str) -> int:
     return int(spec)
 
 
-def synthetic_batches(spec: str, vocab: int, batch_size: int, rank: int, world: int, epoch: int, conditional: bool):
-    """Yields this rank's share of every global batch as the model's x_batch tuple."""
+def flat_batches(spec: str, vocab: int, batch_size: int, rank: int, world: int, epoch: int, conditional: bool):
+    """Yields this rank's share of every global batch as (flat shard, molecule positions, property rows).
+
+    ``synthetic:N[:seed]``: every global batch is drawn from the generator (one seed per (batch, rank): a rank never
+    materialises another rank's molecules).  ``flat:<file.npz>``: a data set written by ``flat.save_shard``, shuffled
+    per epoch with the same permutation on every rank, each rank taking its slice of every global batch."""
     import numpy as np
-    import torch
 
-    from fast_jtnn_hip import parallel, synthetic
-    from fast_jtnn_hip import tensorize as T
+    from fast_jtnn_hip import flat, parallel, synthetic
 
+    lo, hi = parallel.shard_bounds(batch_size, world, rank)
+    if spec.startswith("flat:"):
+        shard, props = flat.load_shard(spec[5:])
+        if conditional and props is None:
+            raise SystemExit("--conditional needs a property table in %s" % spec[5:])
+        order = np.random.RandomState(1000 + epoch).permutation(shard.n)
+        for b0 in range(0, shard.n - batch_size + 1, batch_size):
+            ids = np.sort(order[b0 + lo:b0 + hi])
+            yield shard, ids, (props[ids] if conditional else None)
+        return
     parts = spec.split(":")
     n_total, seed = int(parts[1]), int(parts[2]) if len(parts) > 2 else 0
     for b0 in range(0, n_total - batch_size + 1, batch_size):
-        lo, hi = parallel.shard_bounds(batch_size, world, rank)
-        # one seed per (batch, rank): a rank never materialises another rank's molecules
         trees = synthetic.make_batch(seed * 7919 + epoch * 104729 + b0 * 31 + rank, hi - lo, vocab_size=vocab,
                                      with_cands=True)
-        jt, mess_dict = T.jtenc_tensorize(trees)
-        mp = T.mpn_tensorize([t.mol for t in trees])
-        cands, bi = synthetic.collect_candidates(trees)
-        cj = (T.jtmpn_tensorize(cands, mess_dict), torch.from_numpy(bi))
+        props = None
         if conditional:
             rs = np.random.RandomState(b0 + rank)
             props = np.stack([rs.standard_normal(hi - lo), rs.standard_normal(hi - lo), rs.randint(0, 2, hi - lo),
                               rs.randint(0, 3, hi - lo)], axis=1).astype(np.float32)
-            yield (trees, torch.from_numpy(props), jt, mp, cj)
-        else:
-            yield (trees, jt, mp, cj)
+        yield flat.shard_from_trees(trees, with_cands=True), None, props
 
 
 def main(argv=None):
@@ -106,9 +112,9 @@ def main(argv=None):
     parallel.init_process_group(args.backend, device_index=device.index)
     if args.batch_size % world:
         raise SystemExit("--batch_size %d is not a multiple of %d ranks" % (args.batch_size, world))
-    if not args.train.startswith("synthetic:"):
-        raise SystemExit("--train: only synthetic:N[:seed] is built in; feed real data through "
-                         "fast_jtnn_hip.tensorize from a host that has RDKit")
+    if not args.train.startswith(("synthetic:", "flat:")):
+        raise SystemExit("--train: synthetic:N[:seed] or flat:<file.npz> (fast_jtnn_hip.flat.save_shard; produce it "
+                         "from SMILES on a host that has RDKit)")
     V = vocab_size(args.vocab)
     vocab = synthetic.FakeVocab(V)
     if args.conditional:
@@ -133,12 +139,19 @@ def main(argv=None):
     tr = trainer.Trainer(model, sched, save_dir=args.save_dir, conditional=args.conditional,
                          total_step=args.load_epoch)
     torch.manual_seed(1234 + rank)  # every rank draws its own rsample noise
-    from fast_jtnn_hip.prefetch import Prefetcher, warm_training_batch
+    import torch as _t
+
+    from fast_jtnn_hip import flatprep
+    from fast_jtnn_hip.prefetch import Prefetcher
+
+    def prepare(item):  # native tensorize + index preparation + upload, in a background thread
+        shard, ids, props = item
+        return flatprep.training_batch(model, shard, ids, props=None if props is None else _t.from_numpy(props))
 
     for epoch in range(args.epoch):
-        # the next batch is tensorized, prepared and uploaded by a background thread while this one steps
-        with Prefetcher(synthetic_batches(args.train, V, args.batch_size, rank, world, epoch, args.conditional),
-                        lambda b: warm_training_batch(model, b), device) as loader:  # closed on any exit
+        # the next batches are tensorized, prepared and uploaded by background threads while this one steps
+        with Prefetcher(flat_batches(args.train, V, args.batch_size, rank, world, epoch, args.conditional), prepare,
+                        device) as loader:  # closed on any exit
             for batch in loader:
                 tr.step(batch)
     tr.save("model.epoch-%d" % tr.total_step)  # vae_train.py:146
