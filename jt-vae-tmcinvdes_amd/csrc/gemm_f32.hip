@@ -1031,7 +1031,7 @@ inline TnPlan tn_plan(int M, int N, int K, int ones_col, int max_slab = TN_MAX_S
   int cap = resident / tiles;
   int s = want < cap ? want : cap;
   if (s < 1) s = 1;
-  if (max_slab > 0 && (M + s - 1) / s > max_slab) {
+  if (max_slab > 0 && cap >= 1 && (M + s - 1) / s > max_slab) {
     int rounds = ((M + max_slab - 1) / max_slab + cap - 1) / cap;
     s = rounds * cap;  // whole rounds: a few blocks more than the chip holds would run alone behind a full round
   }
