@@ -41,7 +41,7 @@ KT_STEPS = 5  # serialized steps the per-kernel HIP-event timings are averaged o
 # committed summary of two rocprofv3 --pmc passes over this same command (see the file's "source" field).
 # The summary records the kernel sources it was taken with and the launch count of every kernel; it is used
 # only while both still match, otherwise "traffic" is null.
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 CSRC = os.path.join(ROOT, "jt-vae-tmcinvdes_amd", "csrc")
 
 
