@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 14
+#define JTVAE_ABI_VERSION 15
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -86,7 +86,18 @@ int jtvae_abi_version(void);
 uint64_t jtvae_nt_launch_count(void);
 const char* jtvae_error_string(int code);
 
-/* ---- dense contractions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32) ------------- */
+/* ---- dense contractions on the matrix cores ------------------------------------------- */
+
+/* Form of the large products.  jtvae_gemm_nt with more than ~10 000 rows and jtvae_gemm_tn over at least 4096 rows
+ * (inner extent >= 64, 16-byte aligned operands) run on the bf16 matrix instruction with every fp32 operand split
+ * into three bf16 parts and the six largest cross products accumulated in fp32 (v_mfma_f32_32x32x16_bf16): the
+ * result is as close to the exact product as the fp32 fma chain of v_mfma_f32_32x32x2_f32 (measured against fp64:
+ * 3e-7 against 4e-7 of the result's rms at K = 450), but not bit-identical to it.  Everything smaller stays on the
+ * fp32 instruction.  on = 0 keeps every product on the fp32 instruction, on = 1 restores the default, on < 0 only
+ * queries; returns the setting in force before the call.  Process-wide; the environment variable
+ * JTVAE_SPLIT_BF16=0 sets the initial state.  No counterpart in the reference (torch.nn.Linear picks its own
+ * GEMM kernel by size as well). */
+int jtvae_set_split_products(int on);
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T).  Replaces every nn.Linear call on the path:
  * fast_jtnn/mpn.py:87,93,99; fast_jtnn/jtnn_enc.py:33,115,117-118,124;

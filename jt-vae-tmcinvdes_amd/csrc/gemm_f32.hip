@@ -1,8 +1,11 @@
-// Dense contractions of the encoder path on the CDNA4 fp32 matrix cores.
+// Dense contractions of the encoder path on the CDNA4 matrix cores.
 //
 // v_mfma_f32_32x32x2_f32 is an exact-fp32 fma chain (no reduced-precision fast
 // path exists on gfx950), which is what the 1e-4 parity bound over 20 recurrent
-// GRU iterations needs.  Two kernels:
+// GRU iterations needs; it serves every product up to ~10 000 rows.  The products
+// that fill the chip run in the split form instead (split3 below): fp32 operands
+// cut into three bf16 parts, six bf16 matrix instructions per fp32 one, fp32-class
+// accuracy at 1.4-1.5x the fp32 instruction's throughput.  Two kernels:
 //
 //   gemm_nt : C[M,N] = epilogue(A[M,K] . W[N,K]^T)        forward Linear, and dgrad
 //                                                         with a transposed weight copy
@@ -20,6 +23,7 @@
 // 32x32 accumulators, which keeps the kernel near 128 VGPRs so that four blocks
 // (four waves per SIMD) are resident per CU: the matrix pipe of a SIMD then always has
 // a wave with MFMAs to issue while the others sit in a barrier or stage the next tile.
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
@@ -29,6 +33,9 @@
 using namespace jtvae;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Optional in-kernel timeline of the tiled NT kernel (builds with -DJTVAE_GEMM_TRACE only): lane 0
 // of every wave stamps the shader clock at the phase boundaries of its K loop into a buffer the
@@ -79,6 +86,32 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
   return base + (id >> 3);
 }
+
+// ---------------------------------------------------------------------------------------
+// Split form of the large products.  The fp32 matrix instruction runs at 1/16 of the bf16 one, so a product
+// that fills the chip is computed on the bf16 pipe instead, at fp32 accuracy: every operand is written as the sum
+// of three bf16 numbers, x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2): 3 x 8 = 24
+// significant bits, the residual is below 2^-25 |x|), and the six cross products x_i * y_j with i + j <= 4 are
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are below 2^-23 |x y|; measured against
+// fp64 the result is as close as the fp32 fma chain (1.1e-7 vs 1.7e-7 of sum |x y| at K = 450).  Six bf16
+// instructions of K = 16 replace eight fp32 instructions of K = 2 that take twice as long each.
+__device__ __forceinline__ unsigned pack_bf16(float x, float y) {
+  f32x2 v = {x, y};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32, round to nearest even
+}
+__device__ __forceinline__ void split3(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = pack_bf16(x, y);
+  float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
+  p2 = pack_bf16(rx, ry);
+  rx -= __uint_as_float(p2 << 16);
+  ry -= __uint_as_float(p2 & 0xffff0000u);
+  p3 = pack_bf16(rx, ry);
+}
+// LDS image of a split tile: three planes of [rows][32 k] bf16, 64-byte rows whose four 16-byte chunks are
+// rotated by (row >> 2): the ds_read_b128 of a fragment (16-lane groups of rows that differ in row >> 2) and the
+// ds_write_b64 of the staging (two adjacent rows per 16 lanes) are both free of bank conflicts without padding.
+constexpr int SPLIT_ROW = 64;
+__device__ __forceinline__ int split_off(int row, int chunk) { return row * SPLIT_ROW + 16 * ((chunk + (row >> 2)) & 3); }
 
 struct NtArgs {
   const float* A;
@@ -332,12 +365,19 @@ constexpr int NT_EPI_LD = 40;  // LDS row stride of a wave's 32 x 32 staging til
 // NACC = 32-column accumulators per wave: 3 (block tile 128 x 96) for launches that fill the chip, 1
 // (128 x 32) for mid-size launches, where three times as many, shorter-lived blocks cut the latency
 // chain of a block that has a CU to itself.
-template <bool VEC, int MODE, bool EVEC, int NACC>
+template <int NACC, bool SPLIT>
+constexpr int nt_smem_floats() {
+  return SPLIT ? 3 * (NT_BM + 32 * NACC) * SPLIT_ROW / 4 : (NT_BM + 32 * NACC) * NT_LDS;
+}
+
+template <bool VEC, int MODE, bool EVEC, int NACC, bool SPLIT = false>
 __device__ __forceinline__ void gemm_nt_body(const NtArgs& a, const int block_id, float* smem) {
   constexpr int BN = 32 * NACC;
-  static_assert(4 * 32 * NT_EPI_LD <= (NT_BM + BN) * NT_LDS, "epilogue staging must fit the operand tiles");
+  static_assert(4 * 32 * NT_EPI_LD <= nt_smem_floats<NACC, SPLIT>(), "epilogue staging must fit the operand tiles");
   float* As = smem;
   float* Bs = smem + NT_BM * NT_LDS;
+  unsigned char* planes = reinterpret_cast<unsigned char*>(smem);  // SPLIT: plane p at p * PLANE
+  constexpr int PLANE = (NT_BM + BN) * SPLIT_ROW;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -375,15 +415,33 @@ __device__ __forceinline__ void gemm_nt_body(const NtArgs& a, const int block_id
 #pragma unroll
     for (int i = 0; i < NACC; ++i) rb[i] = load4_raw<VEC>(b_row[i], k0 + 4 * sc4, a.K);
   };
+  // SPLIT: the four values of a staged float4 become three 8-byte groups, one per plane
+  auto put_split = [&](int row, float4 v) {
+    unsigned p1a, p2a, p3a, p1b, p2b, p3b;
+    split3(v.x, v.y, p1a, p2a, p3a);
+    split3(v.z, v.w, p1b, p2b, p3b);
+    const int off = split_off(row, sc4 >> 1) + 8 * (sc4 & 1);
+    *reinterpret_cast<uint2*>(planes + off) = make_uint2(p1a, p1b);
+    *reinterpret_cast<uint2*>(planes + PLANE + off) = make_uint2(p2a, p2b);
+    *reinterpret_cast<uint2*>(planes + 2 * PLANE + off) = make_uint2(p3a, p3b);
+  };
   auto store_tiles = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < NT_BM / 32; ++i)
-      *reinterpret_cast<float4*>(&As[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
-          mask4(ra[i], m0 + srow + 32 * i < a.M, k0 + 4 * sc4, a.K);
+    for (int i = 0; i < NT_BM / 32; ++i) {
+      const float4 v = mask4(ra[i], m0 + srow + 32 * i < a.M, k0 + 4 * sc4, a.K);
+      if (SPLIT)
+        put_split(srow + 32 * i, v);
+      else
+        *reinterpret_cast<float4*>(&As[(srow + 32 * i) * NT_LDS + 4 * sc4]) = v;
+    }
 #pragma unroll
-    for (int i = 0; i < NACC; ++i)
-      *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * NT_LDS + 4 * sc4]) =
-          mask4(rb[i], n0 + srow + 32 * i < a.N, k0 + 4 * sc4, a.K);
+    for (int i = 0; i < NACC; ++i) {
+      const float4 v = mask4(rb[i], n0 + srow + 32 * i < a.N, k0 + 4 * sc4, a.K);
+      if (SPLIT)
+        put_split(NT_BM + srow + 32 * i, v);
+      else
+        *reinterpret_cast<float4*>(&Bs[(srow + 32 * i) * NT_LDS + 4 * sc4]) = v;
+    }
   };
 
   const int nk = (a.K + NT_BK - 1) / NT_BK;
@@ -403,8 +461,36 @@ __device__ __forceinline__ void gemm_nt_body(const NtArgs& a, const int block_id
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) load_tiles((kt + 1) * NT_BK);  // in flight during the MFMAs below
+    if (SPLIT) {
+      // lane (r, h) supplies row r and, in k step s, the eight k values of chunk 2s + h; the six cross products
+      // go into the accumulator smallest first
+      const int r = lane & 31, h = lane >> 5;
+      const int arow = wave * 32 + r;
+      const int ks_end = min(NT_BK / 16, (a.K - kt * NT_BK + 15) >> 4);
+#pragma unroll
+      for (int ks = 0; ks < NT_BK / 16; ++ks) {
+        if (ks >= ks_end) break;
+        const int ao = split_off(arow, 2 * ks + h);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(planes + ao);
+        const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(planes + PLANE + ao);
+        const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(planes + 2 * PLANE + ao);
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) {
+          const int bo = split_off(NT_BM + 32 * t + r, 2 * ks + h);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(planes + bo);
+          const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(planes + PLANE + bo);
+          const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(planes + 2 * PLANE + bo);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+        }
+      }
+    }
     // the last tile of K = 450 holds two valid columns: skip its empty 8-column groups
-    const int kk_end = min(NT_BK / 8, (a.K - kt * NT_BK + 7) >> 3);
+    const int kk_end = SPLIT ? 0 : min(NT_BK / 8, (a.K - kt * NT_BK + 7) >> 3);
 #pragma unroll
     for (int kk = 0; kk < NT_BK / 8; ++kk) {
       if (kk >= kk_end) break;
@@ -487,6 +573,13 @@ template <bool VEC, int MODE, bool EVEC, int NACC>
 __global__ __launch_bounds__(256, 4) void gemm_nt_kernel(NtArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[(NT_BM + 32 * NACC) * NT_LDS];
   gemm_nt_body<VEC, MODE, EVEC, NACC>(a, blockIdx.x, smem);
+}
+
+// the split form: 42 KB of LDS and ~140 registers, three blocks per CU
+template <int MODE, int NACC>
+__global__ __launch_bounds__(256, 3) void gemm_nt_split_kernel(NtArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[nt_smem_floats<NACC, true>()];
+  gemm_nt_body<true, MODE, true, NACC, true>(a, blockIdx.x, smem);
 }
 
 // Two independent products in one launch (blocks [0, a.n_blocks) serve the first): mid-size launches
@@ -850,12 +943,38 @@ __device__ __forceinline__ float4 mask4_ones(float4 v, bool row_ok, int k, int K
 // NACC = 32-column accumulators per wave (k tile 32 * NACC): 3..5 for the wide products, whichever pads K least,
 // 2 / 1 when the reduced-over operand is a narrow feature matrix (K + bias column <= 64 / 32): no MFMA is spent
 // on padding columns.
-template <bool VEC, int NACC>
-__global__ __launch_bounds__(256, NACC >= 4 ? 3 : 2) void gemm_tn_kernel(TnArgs a) {
+// SPLIT (the split form, see split3): the tiles are kept as three bf16 planes in the same m-major layout, and since
+// the bf16 instruction wants eight consecutive m per lane - a column of the image - the fragments come through the
+// transposing LDS read (ds_read_b64_tr_b16: 16 lanes fetch a 4 m x 16 column block and each receives one column).
+// Plane rows are pitched so that the four rows of a block fall into different quarters of the 64 banks.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int TN_XPITCH = TN_BN * 2 + 64;  // bytes per m row of an X plane (256 + 64)
+template <int NACC>
+constexpr int tn_ypitch() { return (64 * NACC) % 256 == 0 ? 64 * NACC + 64 : 64 * NACC; }
+template <int NACC, bool SPLIT>
+constexpr int tn_smem_bytes() {
+  return SPLIT ? 3 * TN_BM * (TN_XPITCH + tn_ypitch<NACC>()) : 4 * TN_BM * (TN_BN + 32 * NACC);
+}
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p1));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool VEC, int NACC, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? (NACC >= 4 ? 2 : 3) : (NACC >= 4 ? 3 : 2)) void gemm_tn_kernel(TnArgs a) {
   constexpr int BKK = 32 * NACC;  // k tile
   constexpr int Y4 = 8 * NACC;    // float4 per staged Y row
-  __shared__ __attribute__((aligned(16))) float Xs[TN_BM * TN_BN];
-  __shared__ __attribute__((aligned(16))) float Ys[TN_BM * BKK];
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[tn_smem_bytes<NACC, SPLIT>()];
+  float* Xs = reinterpret_cast<float*>(smem_raw);
+  float* Ys = Xs + TN_BM * TN_BN;
+  constexpr int YPITCH = tn_ypitch<NACC>();
+  constexpr int XPLANE = TN_BM * TN_XPITCH, YPLANE = TN_BM * YPITCH;
+  unsigned char* Xp = smem_raw;               // SPLIT: X planes, then Y planes
+  unsigned char* Yp = smem_raw + 3 * XPLANE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles = a.tiles_n * a.tiles_k;
   // the tiles of one slab re-read the slab's X and Y rows: keep them on one XCD so that its L2 serves the re-reads
@@ -895,18 +1014,32 @@ __global__ __launch_bounds__(256, NACC >= 4 ? 3 : 2) void gemm_tn_kernel(TnArgs 
     for (int i = 0; i < NACC; ++i)
       ry[i] = load4_raw<VEC>(a.Y + (size_t)iy[i] * a.ldy, k0 + 4 * ((tid + 256 * i) % Y4), a.K);
   };
+  auto put_split = [&](unsigned char* at, int plane, float4 v) {
+    unsigned p1a, p2a, p3a, p1b, p2b, p3b;
+    split3(v.x, v.y, p1a, p2a, p3a);
+    split3(v.z, v.w, p1b, p2b, p3b);
+    *reinterpret_cast<uint2*>(at) = make_uint2(p1a, p1b);
+    *reinterpret_cast<uint2*>(at + plane) = make_uint2(p2a, p2b);
+    *reinterpret_cast<uint2*>(at + 2 * plane) = make_uint2(p3a, p3b);
+  };
   auto store_tiles = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int idx = tid + 256 * i;
-      *reinterpret_cast<float4*>(&Xs[(idx >> 5) * TN_BN + 4 * (idx & 31)]) =
-          mask4(rx[i], mb + (idx >> 5) < m_end, n0 + 4 * (idx & 31), a.N);
+      const float4 v = mask4(rx[i], mb + (idx >> 5) < m_end, n0 + 4 * (idx & 31), a.N);
+      if (SPLIT)
+        put_split(Xp + (idx >> 5) * TN_XPITCH + 8 * (idx & 31), XPLANE, v);
+      else
+        *reinterpret_cast<float4*>(&Xs[(idx >> 5) * TN_BN + 4 * (idx & 31)]) = v;
     }
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
       int idx = tid + 256 * i;
-      *reinterpret_cast<float4*>(&Ys[(idx / Y4) * BKK + 4 * (idx % Y4)]) =
-          mask4_ones(ry[i], mb + idx / Y4 < m_end, k0 + 4 * (idx % Y4), a.K, a.ones_col);
+      const float4 v = mask4_ones(ry[i], mb + idx / Y4 < m_end, k0 + 4 * (idx % Y4), a.K, a.ones_col);
+      if (SPLIT)
+        put_split(Yp + (idx / Y4) * YPITCH + 8 * (idx % Y4), YPLANE, v);
+      else
+        *reinterpret_cast<float4*>(&Ys[(idx / Y4) * BKK + 4 * (idx % Y4)]) = v;
     }
   };
 
@@ -924,8 +1057,34 @@ __global__ __launch_bounds__(256, NACC >= 4 ? 3 : 2) void gemm_tn_kernel(TnArgs 
         load_tiles();                                            // tile mb + TN_BM, rows known already
         if (mb + 2 * TN_BM < m_end) load_rows(mb + 2 * TN_BM);   // row ids of the tile after it
       }
+      if (SPLIT) {
+        // 16-lane group g: columns 16 (g & 1) .. + 16 of the wave's 32, m rows 8 (g >> 1) .. + 8 of the k step, in two
+        // blocks of four; lane 4q + p of a group supplies the address of row q, columns 4p .. 4p + 3
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int mrow = 8 * (g >> 1) + q, col = 16 * (g & 1) + 4 * pp;
 #pragma unroll
-      for (int st = 0; st < TN_BM / 2; ++st) {
+        for (int ks = 0; ks < TN_BM / 16; ++ks) {
+          const unsigned char* xa = Xp + (16 * ks + mrow) * TN_XPITCH + (wave * 32 + col) * 2;
+          const bf16x8 a1 = tr_frag(xa, xa + 4 * TN_XPITCH);
+          const bf16x8 a2 = tr_frag(xa + XPLANE, xa + XPLANE + 4 * TN_XPITCH);
+          const bf16x8 a3 = tr_frag(xa + 2 * XPLANE, xa + 2 * XPLANE + 4 * TN_XPITCH);
+#pragma unroll
+          for (int t = 0; t < NACC; ++t) {
+            const unsigned char* ya = Yp + (16 * ks + mrow) * YPITCH + (32 * t + col) * 2;
+            const bf16x8 b1 = tr_frag(ya, ya + 4 * YPITCH);
+            const bf16x8 b2 = tr_frag(ya + YPLANE, ya + YPLANE + 4 * YPITCH);
+            const bf16x8 b3 = tr_frag(ya + 2 * YPLANE, ya + 2 * YPLANE + 4 * YPITCH);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int st = 0; st < (SPLIT ? 0 : TN_BM / 2); ++st) {
         float xv = xf[2 * st * TN_BN];
         float yv[NACC];
 #pragma unroll
@@ -1005,7 +1164,7 @@ struct TnPlan {
 // M = 5.3 M rows: 98 -> 102 TFLOP/s, and the shorter fp32 chains lose fewer digits).
 constexpr int TN_MAX_SLAB_ROWS = 8192;
 
-inline TnPlan tn_plan(int M, int N, int K, int ones_col, int max_slab = TN_MAX_SLAB_ROWS) {
+inline TnPlan tn_plan(int M, int N, int K, int ones_col, int max_slab = TN_MAX_SLAB_ROWS, bool split = false) {
   TnPlan p;
   const int kk = K + ones_col;
   if (kk <= 64) {
@@ -1027,7 +1186,7 @@ inline TnPlan tn_plan(int M, int N, int K, int ones_col, int max_slab = TN_MAX_S
   int want = (M + 255) / 256;               // at least 256 rows per slab
   // every block does the same work, so the grid is sized to what the chip holds at once (256 CUs x the blocks
   // a CU keeps resident) and never a few blocks more: those would run alone behind a full round
-  int resident = 256 * (p.nacc <= 3 ? 4 : 3);
+  int resident = 256 * (split ? (p.nacc <= 3 ? 3 : 2) : (p.nacc <= 3 ? 4 : 3));
   int cap = resident / tiles;
   int s = want < cap ? want : cap;
   if (s < 1) s = 1;
@@ -1044,7 +1203,16 @@ inline TnPlan tn_plan(int M, int N, int K, int ones_col, int max_slab = TN_MAX_S
   return p;
 }
 
-constexpr int SM_MAX_ROWS = 512;  // above this the tiled kernel fills the chip anyway
+constexpr int SM_MAX_ROWS_DEFAULT = 512;  // above this the tiled kernel fills the chip anyway
+// JTVAE_NT_SMALL_MAX_M overrides it (tests lower it to send small products through the tiled forms)
+int small_max_rows() {
+  static const int v = [] {
+    const char* e = getenv("JTVAE_NT_SMALL_MAX_M");
+    return e ? atoi(e) : SM_MAX_ROWS_DEFAULT;
+  }();
+  return v;
+}
+#define SM_MAX_ROWS small_max_rows()
 
 void launch_nt_small(NtArgs a, hipStream_t s) {
   a.n_tiles_n = (a.N + 31) / 32;
@@ -1076,6 +1244,37 @@ void launch_nt(NtArgs a, hipStream_t s) {
     default:
       hipLaunchKernelGGL((gemm_nt_kernel<VEC, JTVAE_EPI_PLAIN, EVEC, NACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
   }
+}
+
+template <int NACC>
+void launch_nt_split(NtArgs a, hipStream_t s) {
+  a.n_tiles_n = (a.N + 32 * NACC - 1) / (32 * NACC);
+  a.n_blocks = ((a.M + NT_BM - 1) / NT_BM) * a.n_tiles_n;
+  switch (a.e.mode) {
+    case JTVAE_EPI_GRU_BLEND:
+      hipLaunchKernelGGL((gemm_nt_split_kernel<JTVAE_EPI_GRU_BLEND, NACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      break;
+    case JTVAE_EPI_MUL_ACC:
+      hipLaunchKernelGGL((gemm_nt_split_kernel<JTVAE_EPI_MUL_ACC, NACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
+      break;
+    default:
+      hipLaunchKernelGGL((gemm_nt_split_kernel<JTVAE_EPI_PLAIN, NACC>), dim3(a.n_blocks), dim3(256), 0, s, a);
+  }
+}
+
+// Products of more than narrow_max_rows() rows with an inner extent of at least this run in the split form
+// (JTVAE_SPLIT_BF16=0 keeps every product on the fp32 matrix instruction).
+constexpr int SPLIT_MIN_K = 64;
+constexpr int TN_SPLIT_MIN_ROWS = 4096;
+std::atomic<int> split_mode{-1};  // -1: not decided yet (environment), 0 / 1: off / on
+bool split_enabled() {
+  int v = split_mode.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("JTVAE_SPLIT_BF16");
+    v = (e && e[0] == '0') ? 0 : 1;
+    split_mode.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
 }
 
 // Row count up to which the narrow (128 x 32) tiling is used; JTVAE_NT_NARROW_MAX_M overrides it for tuning.
@@ -1142,6 +1341,8 @@ void launch_nt_any(const NtArgs& a, bool vec, hipStream_t s) {
     launch_nt_small(a, s);
   else if (vec && a.evec && a.M <= narrow_max_rows())
     launch_nt<true, true, 1>(a, s);
+  else if (vec && a.evec && a.K >= SPLIT_MIN_K && split_enabled())
+    launch_nt_split<3>(a, s);
   else if (vec && a.evec)
     launch_nt<true, true, 3>(a, s);
   else if (vec)
@@ -1156,9 +1357,13 @@ int gemm_tn_run(const float* X, int32_t ldx, const int32_t* x_rows, const float*
   if (M < 0 || N <= 0 || K <= 0 || ldx < N || ldy < K || lddw < K) return JTVAE_E_SHAPE;
   if (!X || !Y || !dW || !workspace) return JTVAE_E_NULL;
   const int ones_col = dbias ? 1 : 0;
-  TnPlan p = tn_plan(M, N, K, ones_col);
+  const bool vec = aligned16(X, ldx) && aligned16(Y, ldy);
+  // wide products over many rows take the split form (the narrow feature-row products are bound by the rows they
+  // move, short ones by latency)
+  const bool split = vec && split_enabled() && K + ones_col > 64 && M >= TN_SPLIT_MIN_ROWS;
+  TnPlan p = tn_plan(M, N, K, ones_col, TN_MAX_SLAB_ROWS, split);
   if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float))
-    p = tn_plan(M, N, K, ones_col, 0);  // a smaller workspace (the static array) takes one round of longer slabs
+    p = tn_plan(M, N, K, ones_col, 0, split);  // a smaller workspace (the static array) takes one round of longer slabs
   if (workspace_bytes < (size_t)p.splits * N * p.ldp * sizeof(float)) return JTVAE_E_WORKSPACE;
   if (reinterpret_cast<uintptr_t>(workspace) & 15) return JTVAE_E_ALIGN;
   TnArgs a;
@@ -1168,10 +1373,11 @@ int gemm_tn_run(const float* X, int32_t ldx, const int32_t* x_rows, const float*
   a.tiles_n = p.tiles_n; a.tiles_k = p.tiles_k; a.rows_per_split = p.rows_per_split;
   a.ones_col = ones_col;
   int blocks = p.tiles_n * p.tiles_k * p.splits;
-  const bool vec = aligned16(X, ldx) && aligned16(Y, ldy);
 #define JTVAE_TN_LAUNCH(NACC)                                                                   \
   do {                                                                                          \
-    if (vec)                                                                                    \
+    if (split && NACC >= 3)                                                                     \
+      hipLaunchKernelGGL((gemm_tn_kernel<true, (NACC >= 3 ? NACC : 3), true>), dim3(blocks), dim3(256), 0, s, a); \
+    else if (vec)                                                                               \
       hipLaunchKernelGGL((gemm_tn_kernel<true, NACC>), dim3(blocks), dim3(256), 0, s, a);       \
     else                                                                                        \
       hipLaunchKernelGGL((gemm_tn_kernel<false, NACC>), dim3(blocks), dim3(256), 0, s, a);      \
@@ -1355,9 +1561,13 @@ int jtvae_gru_bwd_dh(const float* du, const float* UrT, int32_t ldw, const float
 size_t jtvae_gemm_tn_workspace_bytes(int32_t M, int32_t N, int32_t K) {
   if (M < 0 || N <= 0 || K <= 0) return 0;
   // enough for both forms of the call (with and without the bias column)
-  TnPlan p0 = tn_plan(M, N, K, 0), p1 = tn_plan(M, N, K, 1);
-  size_t s = p0.splits > p1.splits ? p0.splits : p1.splits;
-  return s * N * p0.ldp * sizeof(float);
+  size_t s = 0;
+  for (int split = 0; split < 2; ++split)
+    for (int ones = 0; ones < 2; ++ones) {
+      const size_t n = (size_t)tn_plan(M, N, K, ones, TN_MAX_SLAB_ROWS, split != 0).splits;
+      s = n > s ? n : s;
+    }
+  return s * N * tn_plan(M, N, K, 0).ldp * sizeof(float);
 }
 
 int jtvae_gemm_tn(const float* X, int32_t ldx, const int32_t* x_rows, const float* Y, int32_t ldy,
@@ -1390,6 +1600,12 @@ int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, con
 }
 
 int jtvae_abi_version(void) { return JTVAE_ABI_VERSION; }
+
+int jtvae_set_split_products(int on) {
+  const int before = split_enabled() ? 1 : 0;
+  if (on >= 0) split_mode.store(on ? 1 : 0, std::memory_order_relaxed);
+  return before;
+}
 
 uint64_t jtvae_nt_launch_count(void) { return nt_launches; }
 

@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class Epilogue(C.Structure):
@@ -155,6 +155,7 @@ SIGNATURES = {
     "jtvae_prep_transpose_csr": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_stable_from": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "jtvae_nt_launch_count": (C.c_uint64, []),
+    "jtvae_set_split_products": (C.c_int, [C.c_int]),
     "jtvae_tree_gru_forward": (C.c_int, [_vp, _vp]),
     "jtvae_tree_gru_backward": (C.c_int, [_vp, _vp]),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
@@ -351,6 +352,12 @@ def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0
     _run("gemm_nt", lib.jtvae_gemm_nt, (A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()),
          nbytes=4 * (M * K + N * K + M * N * (1 + extra)), flops=2 * M * N * K,
          tag="M=%d N=%d K=%d mode=%d" % (M, N, K, mode))
+
+
+def set_split_products(on: bool) -> bool:
+    """Large products in the split-bf16 form (default) or on the fp32 matrix instruction; returns the previous
+    setting.  Both are fp32-accurate; they differ in the last bits."""
+    return bool(lib.jtvae_set_split_products(1 if on else 0))
 
 
 def nt_problem(A, lda, W, ldw, Cout, ldc, M, N, K, **epi):

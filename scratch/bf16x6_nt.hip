@@ -1,0 +1,497 @@
+// Feasibility probe: C[M,N] = A[M,K] . W[N,K]^T with fp32 operands split into three bf16 parts each
+// (a = a1 + a2 + a3, 24 significant bits in all) and the six largest cross products a_i * b_j (i + j <= 4)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16: fp32-class accuracy at 16/6 of the fp32 MFMA rate.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/bf16x6_nt scratch/bf16x6_nt.hip && /tmp/bf16x6_nt [M]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BK = 32;
+
+// blocks that share an XCD (ids equal mod 8) get consecutive tiles
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  int q = n >> 3, r = n & 7;
+  int x = id & 7;
+  int base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (id >> 3);
+}
+
+__device__ __forceinline__ unsigned pk(float x, float y) {
+  f32x2 v = {x, y};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(unsigned, h);
+}
+// (x, y) -> three packed bf16 pairs with x = x1 + x2 + x3 (+ 2^-26 |x|)
+__device__ __forceinline__ void split3(float x, float y, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = pk(x, y);
+#ifdef NO_SPLIT
+  p2 = p1; p3 = p1; return;
+#endif
+  float rx = x - __uint_as_float(p1 << 16), ry = y - __uint_as_float(p1 & 0xffff0000u);
+  p2 = pk(rx, ry);
+  rx -= __uint_as_float(p2 << 16);
+  ry -= __uint_as_float(p2 & 0xffff0000u);
+  p3 = pk(rx, ry);
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                    int ldw, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                    int n_tiles_n, unsigned long long* trace, const uint4* __restrict__ Wp, int wp_rows, int wp_ld8) {
+  constexpr int BN = 32 * NACC;
+#ifdef TRACE
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tt = __builtin_readcyclecounter(), tn;
+  const unsigned long long wall0 = wall_clock64(), cyc0 = tt;
+#define PH(i) do { tn = __builtin_readcyclecounter(); tph[i] += tn - tt; tt = tn; } while (0)
+#else
+#define PH(i) do {} while (0)
+#endif
+  constexpr int ROWS = BM + BN;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * ROWS * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / n_tiles_n) * BM, n0 = (tile % n_tiles_n) * BN;
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int srow = tid >> 3, sc4 = tid & 7;
+  float4 ra[BM / 32], rb[NACC];
+  const float* a_row[BM / 32];
+  const float* b_row[NACC];
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i) a_row[i] = A + (size_t)min(m0 + srow + 32 * i, M - 1) * lda;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) b_row[i] = W + (size_t)min(n0 + srow + 32 * i, N - 1) * ldw;
+
+  float4 ra2[BM / 32], rb2[NACC];
+  auto load_into = [&](float4 (&xa)[BM / 32], float4 (&xb)[NACC], int k0) {
+    const int k = k0 + 4 * sc4;
+    const int kc = k < K ? k : 0;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) xa[i] = *reinterpret_cast<const float4*>(a_row[i] + kc);
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) xb[i] = *reinterpret_cast<const float4*>(b_row[i] + kc);
+  };
+  auto put = [&](int row, float4 v, bool row_ok, int k) {
+    v.x = (row_ok && k + 0 < K) ? v.x : 0.f;
+    v.y = (row_ok && k + 1 < K) ? v.y : 0.f;
+    v.z = (row_ok && k + 2 < K) ? v.z : 0.f;
+    v.w = (row_ok && k + 3 < K) ? v.w : 0.f;
+    unsigned p1a, p2a, p3a, p1b, p2b, p3b;
+    split3(v.x, v.y, p1a, p2a, p3a);
+    split3(v.z, v.w, p1b, p2b, p3b);
+    const int off = row * 64 + 16 * (((sc4 >> 1) + (row >> 2)) & 3) + 8 * (sc4 & 1);
+    *reinterpret_cast<uint2*>(smem + off) = make_uint2(p1a, p1b);
+    *reinterpret_cast<uint2*>(smem + ROWS * 64 + off) = make_uint2(p2a, p2b);
+    *reinterpret_cast<uint2*>(smem + 2 * ROWS * 64 + off) = make_uint2(p3a, p3b);
+  };
+  auto store_from = [&](const float4 (&xa)[BM / 32], const float4 (&xb)[NACC], int k0) {
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) put(srow + 32 * i, xa[i], m0 + srow + 32 * i < M, k0 + 4 * sc4);
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) put(BM + srow + 32 * i, xb[i], n0 + srow + 32 * i < N, k0 + 4 * sc4);
+  };
+#ifdef PRESPLIT
+  // W arrives split: three planes [wp_rows][wp_ld8 chunks of 8 bf16], zero padded in both directions; the A side
+  // is read from clamped addresses and never masked (what lies past K meets zeros of W)
+  constexpr int WCH = 3 * BN * 4;  // 16-byte chunks of a W K-tile
+  constexpr int WPT = (WCH + 255) / 256;
+  u32x4 rw[WPT];
+  auto load_w = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = min(tid + 256 * i, WCH - 1);  // unconditional: a guarded load is waited for where it is issued
+      const int plane = c / (BN * 4), rc = c % (BN * 4), row = rc >> 2, ch = rc & 3;
+      rw[i] = reinterpret_cast<const u32x4*>(Wp)[((size_t)plane * wp_rows + n0 + row) * wp_ld8 + (k0 >> 3) + ch];
+    }
+  };
+  auto st_w = [&](int c, u32x4 v) {
+    const int plane = c / (BN * 4), rc = c % (BN * 4), row = BM + (rc >> 2), ch = rc & 3;
+    *reinterpret_cast<u32x4*>(smem + plane * ROWS * 64 + row * 64 + 16 * ((ch + (row >> 2)) & 3)) = v;
+  };
+  auto store_w = [&]() {
+    // threads past the last chunk hold a copy of the last one and store it again: no branch, no guarded access
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) st_w(min(tid + 256 * i, WCH - 1), rw[i]);
+  };
+  auto put_a = [&](int row, float4 v) {
+    unsigned p1a, p2a, p3a, p1b, p2b, p3b;
+    split3(v.x, v.y, p1a, p2a, p3a);
+    split3(v.z, v.w, p1b, p2b, p3b);
+    const int off = row * 64 + 16 * (((sc4 >> 1) + (row >> 2)) & 3) + 8 * (sc4 & 1);
+    *reinterpret_cast<uint2*>(smem + off) = make_uint2(p1a, p1b);
+    *reinterpret_cast<uint2*>(smem + ROWS * 64 + off) = make_uint2(p2a, p2b);
+    *reinterpret_cast<uint2*>(smem + 2 * ROWS * 64 + off) = make_uint2(p3a, p3b);
+  };
+  auto load_tiles = [&](int k0) {
+    const int k = k0 + 4 * sc4;
+    const int kc = k < K ? k : 0;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) ra[i] = *reinterpret_cast<const float4*>(a_row[i] + kc);
+    load_w(k0);
+  };
+  auto store_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) put_a(srow + 32 * i, ra[i]);
+    store_w();
+  };
+#else
+  auto load_tiles = [&](int k0) { load_into(ra, rb, k0); };
+  auto store_tiles = [&](int k0) { store_from(ra, rb, k0); };
+#endif
+
+  const int nk = (K + BK - 1) / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  const int r = lane & 31, h = lane >> 5;
+  const int arow = wave * 32 + r;
+  PH(0);
+  auto mfma_tile = [&](int kt) {
+    const int ks_end = min(2, (K - kt * BK + 15) >> 4);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s >= ks_end) break;
+      const int slot = 2 * s + h;
+      const int aoff = arow * 64 + 16 * ((slot + (arow >> 2)) & 3);
+      bf16x8 a1 = *reinterpret_cast<const bf16x8*>(smem + aoff);
+      bf16x8 a2 = *reinterpret_cast<const bf16x8*>(smem + ROWS * 64 + aoff);
+      bf16x8 a3 = *reinterpret_cast<const bf16x8*>(smem + 2 * ROWS * 64 + aoff);
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) {
+        const int brow = BM + 32 * t + r;
+        const int boff = brow * 64 + 16 * ((slot + (brow >> 2)) & 3);
+        bf16x8 b1 = *reinterpret_cast<const bf16x8*>(smem + boff);
+        bf16x8 b2 = *reinterpret_cast<const bf16x8*>(smem + ROWS * 64 + boff);
+        bf16x8 b3 = *reinterpret_cast<const bf16x8*>(smem + 2 * ROWS * 64 + boff);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+      }
+    }
+  };
+#ifdef DEEP
+  // tile kt + 1 waits in one register set while tile kt + 2 is in flight into the other
+  if (nk > 1) load_into(ra, rb, BK);
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_into(ra2, rb2, (kt + 2) * BK);
+    mfma_tile(kt);
+    PH(1);
+    __syncthreads();
+    PH(2);
+    if (kt + 1 < nk) {
+      store_from(ra, rb, (kt + 1) * BK);
+      PH(3);
+      __syncthreads();
+      PH(4);
+      if (kt + 3 < nk) load_into(ra, rb, (kt + 3) * BK);
+      mfma_tile(kt + 1);
+      PH(1);
+      __syncthreads();
+      PH(2);
+      if (kt + 2 < nk) {
+        store_from(ra2, rb2, (kt + 2) * BK);
+        PH(3);
+        __syncthreads();
+        PH(4);
+      }
+    }
+  }
+#else
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles((kt + 1) * BK);
+    mfma_tile(kt);
+    PH(1);
+    __syncthreads();
+    PH(2);
+    if (more) {
+      store_tiles((kt + 1) * BK);
+      PH(3);
+      __syncthreads();
+      PH(4);
+    }
+  }
+#endif
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (i >= M) continue;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+      const int n = n0 + 32 * t + r;
+      if (n < N) C[(size_t)i * ldc + n] = acc[t][q];
+    }
+  }
+#ifdef TRACE
+  __builtin_amdgcn_s_waitcnt(0);
+  PH(5);
+  if (lane == 0 && blockIdx.x == 1000 && wave == 0)
+    printf("block 1000: %llu shader cycles in %llu ticks of the 100 MHz wall clock\n", tt - cyc0, wall_clock64() - wall0);
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) trace[((size_t)blockIdx.x * 4 + wave) * 6 + i] = tph[i];
+#endif
+}
+
+
+// v2: the A operand never touches LDS.  Lane (r, h) of a wave owns row r of the wave's 32 rows and, per K tile of
+// 32, the 16 consecutive k values [16h, 16h + 16) of it (k step s takes the 8 starting at 16h + 8s; W's image uses
+// the same permutation), loads them as 64 contiguous bytes and splits them in registers.  W arrives pre-split and
+// goes through a double-buffered LDS image: one barrier per K tile.
+template <int NACC>
+__global__ __launch_bounds__(256, NACC > 3 ? 2 : 3) void nt_v2(const float* __restrict__ A, int lda, float* __restrict__ C, int ldc,
+                                                int M, int N, int K, int n_tiles_n, const u32x4* __restrict__ Wp,
+                                                int wp_rows, int wp_ld8) {
+  constexpr int BN = 32 * NACC;
+  constexpr int WCH = 3 * BN * 4;  // 16-byte chunks of a W K-tile
+  constexpr int WPT = (WCH + 255) / 256;
+  constexpr int WBUF = 3 * BN * 64;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WBUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / n_tiles_n) * BM, n0 = (tile % n_tiles_n) * BN;
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+#ifdef SAME_A
+  const float* a_row = A + (size_t)min((m0 & 1023) + wave * 32 + r, M - 1) * lda + 16 * h;
+#else
+  const float* a_row = A + (size_t)min(m0 + wave * 32 + r, M - 1) * lda + 16 * h;
+#endif
+  float4 ra[4];
+  u32x4 rw[WPT];
+  const int nk = (K + BK - 1) / BK;
+  auto load_a = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = kt * BK + 16 * h + 4 * i;
+      ra[i] = *reinterpret_cast<const float4*>(a_row + (k + 3 < lda ? kt * BK + 4 * i : -16 * h));
+    }
+  };
+  auto load_w = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = min(tid + 256 * i, WCH - 1);
+      const int plane = c / (BN * 4), rc = c % (BN * 4), row = rc >> 2, ch = rc & 3;
+      rw[i] = Wp[((size_t)plane * wp_rows + n0 + row) * wp_ld8 + kt * 4 + ch];
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = min(tid + 256 * i, WCH - 1);
+      const int plane = c / (BN * 4), rc = c % (BN * 4), row = rc >> 2, ch = rc & 3;
+      *reinterpret_cast<u32x4*>(smem + buf * WBUF + (plane * BN + row) * 64 + 16 * ((ch + (row >> 2)) & 3)) = rw[i];
+    }
+  };
+  load_a(0);
+  load_w(0);
+  store_w(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    // this tile's A values -> three fragments per k step
+    float4 v[4] = {ra[0], ra[1], ra[2], ra[3]};
+    if (kt == nk - 1 && (K & 31)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = kt * BK + 16 * h + 4 * i;
+        v[i].x = k + 0 < K ? v[i].x : 0.f;
+        v[i].y = k + 1 < K ? v[i].y : 0.f;
+        v[i].z = k + 2 < K ? v[i].z : 0.f;
+        v[i].w = k + 3 < K ? v[i].w : 0.f;
+      }
+    }
+    if (more) {
+      load_a(kt + 1);
+      load_w(kt + 1);
+    }
+    const unsigned char* wb = smem + (kt & 1) * WBUF;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      unsigned p[3][4];
+      split3(v[2 * s].x, v[2 * s].y, p[0][0], p[1][0], p[2][0]);
+      split3(v[2 * s].z, v[2 * s].w, p[0][1], p[1][1], p[2][1]);
+      split3(v[2 * s + 1].x, v[2 * s + 1].y, p[0][2], p[1][2], p[2][2]);
+      split3(v[2 * s + 1].z, v[2 * s + 1].w, p[0][3], p[1][3], p[2][3]);
+      u32x4 q1 = {p[0][0], p[0][1], p[0][2], p[0][3]};
+      u32x4 q2 = {p[1][0], p[1][1], p[1][2], p[1][3]};
+      u32x4 q3 = {p[2][0], p[2][1], p[2][2], p[2][3]};
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, q1), a2 = __builtin_bit_cast(bf16x8, q2),
+                   a3 = __builtin_bit_cast(bf16x8, q3);
+      const int slot = 2 * h + s;  // chunk of W's row that holds k = 16h + 8s .. + 8
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) {
+        const int brow = 32 * t + r;
+#ifdef NO_LDSREAD
+        const int boff = 0;
+#else
+        const int boff = brow * 64 + 16 * ((slot + (brow >> 2)) & 3);
+#endif
+        bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wb + boff);
+        bf16x8 b2 = *reinterpret_cast<const bf16x8*>(wb + BN * 64 + boff);
+        bf16x8 b3 = *reinterpret_cast<const bf16x8*>(wb + 2 * BN * 64 + boff);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) store_w((kt + 1) & 1);
+#ifndef NO_BARRIER
+    __syncthreads();
+#endif
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (i >= M) continue;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+      const int n = n0 + 32 * t + r;
+#ifdef NO_STORE
+      if (n < N && acc[t][q] == 123.456f) C[(size_t)i * ldc + n] = acc[t][q];
+#else
+      if (n < N) C[(size_t)i * ldc + n] = acc[t][q];
+#endif
+    }
+  }
+}
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                 \
+    }                                                                          \
+  } while (0)
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 85181, N = 450, K = 450, ld = 452;
+  std::vector<float> hA((size_t)M * ld, 0.f), hW((size_t)N * ld, 0.f), hC((size_t)M * ld);
+  unsigned s = 12345u;
+  auto rnd = [&]() {
+    s = s * 1664525u + 1013904223u;
+    unsigned hi = s >> 8;  // 24 random bits
+    s = s * 1664525u + 1013904223u;
+    return (float)(((double)hi + (double)(s >> 8) / 16777216.0) / 8388608.0 - 1.0);  // full 24-bit significands
+  };
+  for (int i = 0; i < M; ++i)
+    for (int k = 0; k < K; ++k) hA[(size_t)i * ld + k] = rnd() * (1.f + (i % 7));
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) hW[(size_t)n * ld + k] = rnd() * 0.05f;
+  float *dA, *dW, *dC;
+  CK(hipMalloc(&dA, hA.size() * 4));
+  CK(hipMalloc(&dW, hW.size() * 4));
+  CK(hipMalloc(&dC, hC.size() * 4));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(dC, 0, hC.size() * 4));
+#ifndef NACC_
+#define NACC_ 3
+#endif
+  constexpr int NACC = NACC_;
+  const int ntn = (N + 32 * NACC - 1) / (32 * NACC), ntm = (M + BM - 1) / BM;
+  const int wp_rows = 480, wp_ld8 = 480 / 8;
+  std::vector<unsigned short> hWp((size_t)3 * wp_rows * 480, 0);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      float x = hW[(size_t)n * ld + k];
+      for (int pl = 0; pl < 3; ++pl) {
+        unsigned u;
+        memcpy(&u, &x, 4);
+        unsigned rnd_ = ((u >> 16) & 1) + 0x7fffu;
+        unsigned short hb = (unsigned short)((u + rnd_) >> 16);
+        hWp[((size_t)pl * wp_rows + n) * 480 + k] = hb;
+        unsigned back = (unsigned)hb << 16;
+        float fb;
+        memcpy(&fb, &back, 4);
+        x -= fb;
+      }
+    }
+  uint4* dWp;
+  CK(hipMalloc(&dWp, hWp.size() * 2));
+  CK(hipMemcpy(dWp, hWp.data(), hWp.size() * 2, hipMemcpyHostToDevice));
+  unsigned long long* dT;
+  CK(hipMalloc(&dT, (size_t)ntm * ntn * 4 * 6 * 8));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const bool use_v2 = getenv("V2") != nullptr;
+  auto launch = [&]() {
+    if (use_v2)
+      hipLaunchKernelGGL(nt_v2<NACC>, dim3(ntm * ntn), dim3(256), 0, 0, dA, ld, dC, ld, M, N, K, ntn,
+                         (const u32x4*)dWp, wp_rows, wp_ld8);
+    else
+      hipLaunchKernelGGL(nt_bf16x6<NACC>, dim3(ntm * ntn), dim3(256), 0, 0, dA, ld, dW, ld, dC, ld, M, N, K, ntn, dT, dWp, wp_rows, wp_ld8);
+  };
+  for (int it = 0; it < (getenv("WARM") ? atoi(getenv("WARM")) : 3); ++it)
+    launch();
+  CK(hipDeviceSynchronize());
+  const int reps = 20;
+  CK(hipEventRecord(e0));
+  for (int it = 0; it < reps; ++it) launch();
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= reps;
+  printf("M=%d N=%d K=%d  %.1f us  %.1f TFLOP/s (fp32-equivalent)\n", M, N, K, ms * 1e3,
+         2.0 * M * N * K / (ms * 1e-3) / 1e12);
+  CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+#ifdef TRACE
+  {
+    std::vector<unsigned long long> hT((size_t)ntm * ntn * 4 * 6);
+    CK(hipMemcpy(hT.data(), dT, hT.size() * 8, hipMemcpyDeviceToHost));
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t w = 0; w < (size_t)ntm * ntn * 4; ++w)
+      for (int i = 0; i < 6; ++i) ph[i] += hT[w * 6 + i];
+    const char* nm[6] = {"prologue", "frag reads + mfma issue", "barrier 1", "wait global + split + lds store", "barrier 2", "epilogue"};
+    for (int i = 0; i < 6; ++i) printf("  %-34s %9.0f cycles per wave (whole block life)\n", nm[i], ph[i] / (ntm * ntn * 4.0));
+  }
+#endif
+  // accuracy against fp64 on a sample of rows, beside a plain fp32 fma chain
+  double worst = 0, worst32 = 0;
+  for (int i = 0; i < M; i += 997) {
+    for (int n = 0; n < N; n += 7) {
+      double ref = 0, mag = 0;
+      float c32 = 0.f;
+      for (int k = 0; k < K; ++k) {
+        double p = (double)hA[(size_t)i * ld + k] * hW[(size_t)n * ld + k];
+        ref += p;
+        mag += fabs(p);
+        c32 = fmaf(hA[(size_t)i * ld + k], hW[(size_t)n * ld + k], c32);
+      }
+      worst = fmax(worst, fabs(hC[(size_t)i * ld + n] - ref) / mag);
+      worst32 = fmax(worst32, fabs(c32 - ref) / mag);
+    }
+  }
+  printf("max |err| / sum|a b|: split-bf16 %.3e   fp32 fma chain %.3e\n", worst, worst32);
+  return 0;
+}

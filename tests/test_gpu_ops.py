@@ -686,3 +686,90 @@ def test_onehot_linear_forward_and_weight_gradient(n_rows, F, H):
     assert np.abs(grads[0] - want_dw).max() <= 2e-5 * scale
     assert np.abs(grads[2] - (want_dw + init.cpu().numpy())).max() <= 2e-5 * scale
     assert K.lib.jtvae_onehot_linear(16, 4, 400, 16, 452, None, 16, 452, 450, None) == K.E_WORKSPACE  # table too big
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [10001, 20480, 33333])
+def test_large_products_in_split_form_are_fp32_accurate(K, M):
+    """Products of more than ~10 000 rows run on the bf16 matrix instruction with operands split into three bf16
+    parts (jtvae_set_split_products).  Against fp64 they must be as accurate as the fp32 instruction's fma chain:
+    both within 2e-6 of sum |a w| per element, the split form's rms error within 1.5x of the fp32 form's; gathered /
+    scattered rows, bias, addend and activation behave as in the fp32 form; padding columns stay zero."""
+    import torch
+    H, ld = 450, 452
+    g = torch.Generator(device="cuda").manual_seed(M)
+    A = torch.zeros(M, ld, device="cuda")
+    A[:, :H] = torch.relu(torch.randn(M, H, device="cuda", generator=g)) * torch.exp(torch.randn(M, H, device="cuda", generator=g))
+    A[:, H:] = float("nan")  # padding columns of an input may hold anything
+    W = torch.zeros(H, ld, device="cuda")
+    W[:, :H] = 0.05 * torch.randn(H, H, device="cuda", generator=g)
+    ref = A[:, :H].double() @ W[:, :H].double().t()
+    mag = A[:, :H].double().abs() @ W[:, :H].double().abs().t()
+    out = {}
+    for on in (True, False):
+        was = K.set_split_products(on)
+        try:
+            C_ = torch.full((M, ld), 7.0, device="cuda")
+            K.gemm_nt(A.data_ptr(), ld, W.data_ptr(), ld, C_.data_ptr(), ld, M, H, H)
+            torch.cuda.synchronize()
+        finally:
+            K.set_split_products(was)
+        assert bool((C_[:, H:] == 0).all())
+        err = (C_[:, :H].double() - ref).abs()
+        assert float((err / mag).max()) < 2e-6, on
+        out[on] = (C_, float(err.pow(2).mean().sqrt()))
+    assert out[True][1] < 1.5 * out[False][1]
+    assert not torch.equal(out[True][0], out[False][0])  # two forms, not one kernel under two names
+    # row lists + bias + addend + activation through the split form
+    rows = torch.randperm(M, device="cuda", generator=g)[: M - 37].to(torch.int32).contiguous()
+    bias = torch.randn(H, device="cuda", generator=g)
+    add = torch.zeros(M, ld, device="cuda")
+    add[:, :H] = torch.randn(M, H, device="cuda", generator=g)
+    C_ = torch.zeros(M, ld, device="cuda")
+    K.gemm_nt(A.data_ptr(), ld, W.data_ptr(), ld, C_.data_ptr(), ld, rows.numel(), H, H, bias=bias.data_ptr(),
+              add=add.data_ptr(), ld_add=ld, act=K.ACT_TANH, a_rows=rows.data_ptr(), c_rows=rows.data_ptr())
+    torch.cuda.synchronize()
+    r = rows.long()
+    want = torch.tanh(ref[r] + bias.double() + add[r, :H].double())
+    assert float((C_[r, :H].double() - want).abs().max()) < 2e-5
+    untouched = torch.ones(M, dtype=torch.bool, device="cuda")
+    untouched[r] = False
+    assert bool((C_[untouched] == 0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [4096, 40898, 100003])
+def test_weight_gradient_in_split_form_is_fp32_accurate(K, M):
+    """jtvae_gemm_tn over >= 4096 rows in the split form (transposing LDS reads feed the bf16 instruction): against
+    fp64 as accurate as the fp32 form to a factor of 2.5 in rms, bias column and row-pair lists included."""
+    import torch
+    H, ld = 450, 452
+    g = torch.Generator(device="cuda").manual_seed(M)
+    X = torch.zeros(M, ld, device="cuda")
+    X[:, :H] = torch.randn(M, H, device="cuda", generator=g) * (torch.rand(M, H, device="cuda", generator=g) < 0.5)
+    Y = torch.zeros(M, ld, device="cuda")
+    Y[:, :H] = torch.relu(torch.randn(M, H, device="cuda", generator=g))
+    xr = torch.randint(0, M, (M,), device="cuda", dtype=torch.int32, generator=g)
+    yr = torch.randint(0, M, (M,), device="cuda", dtype=torch.int32, generator=g)
+    ref = X[:, :H].double().t() @ Y[:, :H].double()
+    ref_b = X[:, :H].double().sum(0)
+    ref_p = X[xr.long(), :H].double().t() @ Y[yr.long(), :H].double()
+    rms = {}
+    for on in (True, False):
+        was = K.set_split_products(on)
+        try:
+            dW = torch.empty(H, H, device="cuda")
+            db = torch.empty(H, device="cuda")
+            K.gemm_tn(X.data_ptr(), ld, Y.data_ptr(), ld, dW.data_ptr(), H, M, H, H, False, "cuda", dbias=db.data_ptr())
+            dP = torch.empty(H, H, device="cuda")
+            K.gemm_tn(X.data_ptr(), ld, Y.data_ptr(), ld, dP.data_ptr(), H, M, H, H, False, "cuda",
+                      x_rows=xr.data_ptr(), y_rows=yr.data_ptr())
+            torch.cuda.synchronize()
+        finally:
+            K.set_split_products(was)
+        e = float((dW.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        eb = float((db.double() - ref_b).abs().max() / ref_b.abs().max())
+        ep = float((dP.double() - ref_p).pow(2).mean().sqrt() / ref_p.pow(2).mean().sqrt())
+        assert e < 2e-6 and eb < 1e-6 and ep < 2e-6, (on, e, eb, ep)
+        rms[on] = e
+    assert rms[True] < 2.5 * rms[False]

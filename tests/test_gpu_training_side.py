@@ -235,8 +235,14 @@ def test_full_training_step_at_batch_4096_is_the_mean_of_its_halves():
     """The full-step configuration (4096 molecules per GPU, JTNNVAE.forward + backward + clip + Adam through
     the trainer).  No CPU oracle finishes this size in seconds, so the check is the path's linearity: every
     loss term is a sum over molecules divided by the batch size (fast_jtnn/jtnn_vae.py:85-103, 137;
-    jtnn_dec.py:183-190), hence loss and gradients of the batch are the means of those of its two halves."""
-    from fast_jtnn_hip import synthetic, tensorize as T, trainer
+    jtnn_dec.py:183-190), hence loss and gradients of the batch are the means of those of its two halves.
+
+    The linearity is checked with every product on the fp32 matrix instruction, where batch and halves run the same
+    fma chains (1e-4).  The default form of the large products (fp32 operands split into bf16 parts) rounds
+    differently in the last bits, and this model's gradients amplify last-bit differences (ReLU units at the
+    switching point: the reference's own fp32 run deviates from its fp64 run by up to 2.8e-3 on the golden
+    cases), so the default form is held to the fp32 form at 1e-5 on the loss and 2e-3 on every gradient."""
+    from fast_jtnn_hip import _capi, synthetic, tensorize as T, trainer
 
     B, V = 4096, 385
     trees = synthetic.make_batch(4242, B, vocab_size=V, mean_atoms=40.0, with_cands=True)
@@ -265,10 +271,20 @@ def test_full_training_step_at_batch_4096_is_the_mean_of_its_halves():
         return ([float(out[0].item()), float(out[1])] + [float(v) for v in out[2:]],
                 {n: p.grad.detach().clone() for n, p in m.named_parameters()})
 
-    full, g_full = run(0, B)
-    a, g_a = run(0, B // 2)
-    b, g_b = run(B // 2, B)
-    assert all(np.isfinite(full))
+    full_split, g_split = run(0, B)  # default: large products in the split form
+    was = _capi.set_split_products(False)
+    try:
+        full, g_full = run(0, B)
+        a, g_a = run(0, B // 2)
+        b, g_b = run(B // 2, B)
+    finally:
+        _capi.set_split_products(was)
+    assert was, "the split form is the default"
+    assert all(np.isfinite(full)) and all(np.isfinite(full_split))
+    assert close(full_split[0], full[0], 1e-5) and close(full_split[1], full[1], 1e-5)
+    for name, gf in g_full.items():
+        err = float((g_split[name] - gf).norm() / gf.norm().clamp_min(1e-30))
+        assert err < 2e-3, (name, err)
     assert close(full[0], 0.5 * (a[0] + b[0]), 1e-5) and close(full[1], 0.5 * (a[1] + b[1]), 1e-5)
     for name, gf in g_full.items():
         mean = 0.5 * (g_a[name] + g_b[name])
@@ -280,7 +296,8 @@ def test_full_training_step_at_batch_4096_is_the_mean_of_its_halves():
     tr = trainer.Trainer(m, trainer.Schedule(beta=beta, print_iter=10 ** 9, save_iter=10 ** 9, anneal_iter=10 ** 9,
                                              kl_anneal_iter=10 ** 9), log=lambda *a: None)
     res = tr.step(x_batch(trees), epsilons=eps)
-    assert res.ok and close(res.loss, full[0], 1e-5)
+    assert res.ok and close(res.loss, full_split[0], 1e-5)
+    g_full = g_split  # the trainer ran in the default form, like the first run above
     total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in g_full.values())))
     moved = 0
     for name, p in m.named_parameters():
