@@ -21,7 +21,8 @@ from collections import OrderedDict
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libjtvae_hip.so")
+# JTVAE_HIP_LIB: another build of the library (same ABI), e.g. to compare two kernel versions in one session
+LIB_PATH = os.environ.get("JTVAE_HIP_LIB") or os.path.join(_HERE, "libjtvae_hip.so")
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2

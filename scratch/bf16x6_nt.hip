@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
 #define PH(i) do {} while (0)
 #endif
   constexpr int ROWS = BM + BN;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * ROWS * 64];
+#ifndef LDS_PAD
+#define LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * ROWS * 64 + LDS_PAD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (tile / n_tiles_n) * BM, n0 = (tile % n_tiles_n) * BN;
@@ -168,14 +171,22 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
     for (int s = 0; s < 2; ++s) {
       if (s >= ks_end) break;
       const int slot = 2 * s + h;
+#ifdef V1_NO_LDSREAD
+      const int aoff = 0;
+#else
       const int aoff = arow * 64 + 16 * ((slot + (arow >> 2)) & 3);
+#endif
       bf16x8 a1 = *reinterpret_cast<const bf16x8*>(smem + aoff);
       bf16x8 a2 = *reinterpret_cast<const bf16x8*>(smem + ROWS * 64 + aoff);
       bf16x8 a3 = *reinterpret_cast<const bf16x8*>(smem + 2 * ROWS * 64 + aoff);
 #pragma unroll
       for (int t = 0; t < NACC; ++t) {
         const int brow = BM + 32 * t + r;
+#ifdef V1_NO_LDSREAD
+        const int boff = 0;
+#else
         const int boff = brow * 64 + 16 * ((slot + (brow >> 2)) & 3);
+#endif
         bf16x8 b1 = *reinterpret_cast<const bf16x8*>(smem + boff);
         bf16x8 b2 = *reinterpret_cast<const bf16x8*>(smem + ROWS * 64 + boff);
         bf16x8 b3 = *reinterpret_cast<const bf16x8*>(smem + 2 * ROWS * 64 + boff);
@@ -195,12 +206,16 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
     if (kt + 2 < nk) load_into(ra2, rb2, (kt + 2) * BK);
     mfma_tile(kt);
     PH(1);
+#ifndef V1_NO_BARRIER
     __syncthreads();
+#endif
     PH(2);
     if (kt + 1 < nk) {
       store_from(ra, rb, (kt + 1) * BK);
       PH(3);
+#ifndef V1_NO_BARRIER
       __syncthreads();
+#endif
       PH(4);
       if (kt + 3 < nk) load_into(ra, rb, (kt + 3) * BK);
       mfma_tile(kt + 1);
@@ -221,12 +236,16 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
     if (more) load_tiles((kt + 1) * BK);
     mfma_tile(kt);
     PH(1);
+#ifndef V1_NO_BARRIER
     __syncthreads();
+#endif
     PH(2);
     if (more) {
       store_tiles((kt + 1) * BK);
       PH(3);
+#ifndef V1_NO_BARRIER
       __syncthreads();
+#endif
       PH(4);
     }
   }
@@ -238,7 +257,11 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
       const int n = n0 + 32 * t + r;
+#ifdef NO_STORE
+      if (n < N && acc[t][q] == 123.456f) C[(size_t)i * ldc + n] = acc[t][q];
+#else
       if (n < N) C[(size_t)i * ldc + n] = acc[t][q];
+#endif
     }
   }
 #ifdef TRACE
