@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
                                                     int n_tiles_n, unsigned long long* trace, const uint4* __restrict__ Wp, int wp_rows, int wp_ld8) {
   constexpr int BN = 32 * NACC;
 #ifdef TRACE
-  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tt = __builtin_readcyclecounter(), tn;
+  unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tt = __builtin_readcyclecounter(), tn;
   const unsigned long long wall0 = wall_clock64(), cyc0 = tt;
 #define PH(i) do { tn = __builtin_readcyclecounter(); tph[i] += tn - tt; tt = tn; } while (0)
 #else
@@ -165,6 +165,45 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
   const int r = lane & 31, h = lane >> 5;
   const int arow = wave * 32 + r;
   PH(0);
+#ifdef LOOKAHEAD
+  // fragments one group of six matrix instructions ahead: A of both k steps up front, B of group g + 1 requested
+  // before the instructions of group g are issued
+  auto mfma_tile = [&](int kt) {
+    const int ks_end = min(2, (K - kt * BK + 15) >> 4);
+    bf16x8 af[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int slot = 2 * s + h;
+      const int aoff = arow * 64 + 16 * ((slot + (arow >> 2)) & 3);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[s][p] = *reinterpret_cast<const bf16x8*>(smem + p * ROWS * 64 + aoff);
+    }
+    auto ldb = [&](int g, bf16x8 (&b)[3]) {
+      const int s = g / NACC, t = g % NACC;
+      const int brow = BM + 32 * t + r;
+      const int boff = brow * 64 + 16 * ((2 * s + h + (brow >> 2)) & 3);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(smem + p * ROWS * 64 + boff);
+    };
+    bf16x8 bq[2][3];
+    ldb(0, bq[0]);
+    const int groups = ks_end * NACC;
+#pragma unroll
+    for (int g = 0; g < 2 * NACC; ++g) {
+      if (g >= groups) break;
+      if (g + 1 < 2 * NACC) ldb(g + 1, bq[(g + 1) & 1]);
+      const int s = g / NACC, t = g % NACC;
+      const bf16x8 (&b)[3] = bq[g & 1];
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][2], b[0], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], b[2], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], b[1], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1], b[0], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], b[1], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0], b[0], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#else
   auto mfma_tile = [&](int kt) {
     const int ks_end = min(2, (K - kt * BK + 15) >> 4);
 #pragma unroll
@@ -199,6 +238,7 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
       }
     }
   };
+#endif
 #ifdef DEEP
   // tile kt + 1 waits in one register set while tile kt + 2 is in flight into the other
   if (nk > 1) load_into(ra, rb, BK);
@@ -270,7 +310,7 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
   if (lane == 0 && blockIdx.x == 1000 && wave == 0)
     printf("block 1000: %llu shader cycles in %llu ticks of the 100 MHz wall clock\n", tt - cyc0, wall_clock64() - wall0);
   if (lane == 0)
-    for (int i = 0; i < 6; ++i) trace[((size_t)blockIdx.x * 4 + wave) * 6 + i] = tph[i];
+    for (int i = 0; i < 8; ++i) trace[((size_t)blockIdx.x * 4 + wave) * 8 + i] = tph[i];
 #endif
 }
 
@@ -406,6 +446,138 @@ __global__ __launch_bounds__(256, NACC > 3 ? 2 : 3) void nt_v2(const float* __re
   }
 }
 
+// v3: K steps of 16 through a two-stage LDS ring.  While the matrix instructions of step s run from stage s & 1, the
+// same wave splits the (already arrived) global values of step s + 1 and writes them into the other stage, in program
+// order between the groups of matrix instructions, and the loads of step s + 2 are in flight: one barrier per step,
+// and no phase in which a block does nothing but stage.
+template <int NACC>
+__global__ __launch_bounds__(256, 3) void nt_v3(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                int ldw, float* __restrict__ C, int ldc, int M, int N, int K,
+                                                int n_tiles_n) {
+  constexpr int BN = 32 * NACC;
+  constexpr int ROWS = BM + BN;
+  constexpr int PLANE = ROWS * 32;  // bytes: 16 bf16 per row
+  constexpr int STAGE = 3 * PLANE;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / n_tiles_n) * BM, n0 = (tile % n_tiles_n) * BN;
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  // staging: four threads per row (4 k each), rows tid >> 2 and + 64 of the A tile; W rows (tid >> 2) and, for the
+  // first half of the block, 64 + (tid >> 2) (the second half repeats row 95's last store: same bytes, no branch)
+  const int srow = tid >> 2, kc = tid & 3;
+  constexpr int NW = (BN * 4 + 255) / 256;
+  const float* a_ptr[2];
+  const float* w_ptr[NW];
+  int a_off[2], w_off[NW];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = srow + 64 * i;
+    a_ptr[i] = A + (size_t)min(m0 + row, M - 1) * lda + 4 * kc;
+    a_off[i] = row * 32 + 16 * ((kc >> 1) ^ ((row >> 3) & 1)) + 8 * (kc & 1);
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int row = min(srow + 64 * i, BN - 1);
+    w_ptr[i] = W + (size_t)min(n0 + row, N - 1) * ldw + 4 * kc;
+    w_off[i] = (BM + row) * 32 + 16 * ((kc >> 1) ^ (((BM + row) >> 3) & 1)) + 8 * (kc & 1);
+  }
+  const int ns = (K + 15) >> 4;
+  float4 ga[2][2], gw[2][NW];  // [register set][item]
+  auto gload = [&](int set, int s) {
+    // the last step reaches past K: its loads come from column 0 instead and are zeroed when consumed
+    const int k0 = (16 * s + 4 * kc + 3 < lda && 16 * s + 4 * kc + 3 < ldw) ? 16 * s : -4 * kc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ga[set][i] = *reinterpret_cast<const float4*>(a_ptr[i] + k0);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) gw[set][i] = *reinterpret_cast<const float4*>(w_ptr[i] + k0);
+  };
+  auto put = [&](unsigned char* stage, int off, float4 v, int s) {
+    if (16 * s + 16 > K) {  // uniform: only the last step
+      const int k = 16 * s + 4 * kc;
+      v.x = k + 0 < K ? v.x : 0.f;
+      v.y = k + 1 < K ? v.y : 0.f;
+      v.z = k + 2 < K ? v.z : 0.f;
+      v.w = k + 3 < K ? v.w : 0.f;
+    }
+    unsigned p1a, p2a, p3a, p1b, p2b, p3b;
+    split3(v.x, v.y, p1a, p2a, p3a);
+    split3(v.z, v.w, p1b, p2b, p3b);
+    *reinterpret_cast<uint2*>(stage + off) = make_uint2(p1a, p1b);
+    *reinterpret_cast<uint2*>(stage + PLANE + off) = make_uint2(p2a, p2b);
+    *reinterpret_cast<uint2*>(stage + 2 * PLANE + off) = make_uint2(p3a, p3b);
+  };
+  const int a_frag = (wave * 32 + r) * 32 + 16 * (h ^ (((wave * 32 + r) >> 3) & 1));
+  int b_frag[NACC];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t) b_frag[t] = (BM + 32 * t + r) * 32 + 16 * (h ^ (((BM + 32 * t + r) >> 3) & 1));
+
+  auto step = [&](int s, int set_next) {
+    // set_next holds the values of step s + 1 (if any); the other set is free for the loads of step s + 2
+    const unsigned char* cur = smem + (s & 1) * STAGE;
+    unsigned char* nxt = smem + ((s + 1) & 1) * STAGE;
+    const bool has_next = s + 1 < ns;
+    if (s + 2 < ns) gload(set_next ^ 1, s + 2);
+    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(cur + a_frag);
+    const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(cur + PLANE + a_frag);
+    const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(cur + 2 * PLANE + a_frag);
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(cur + b_frag[t]);
+      const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(cur + PLANE + b_frag[t]);
+      const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(cur + 2 * PLANE + b_frag[t]);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+      // a share of the next step's staging behind each group of six
+      if (has_next) {
+        if (t == 0) {
+          put(nxt, a_off[0], ga[set_next][0], s + 1);
+          put(nxt, a_off[1], ga[set_next][1], s + 1);
+        } else if (t - 1 < NW) {
+          put(nxt, w_off[t - 1], gw[set_next][t - 1], s + 1);
+        }
+      }
+#ifdef V3_SCHED
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    __syncthreads();
+  };
+
+  gload(0, 0);
+  if (ns > 1) gload(1, 1);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) put(smem, a_off[i], ga[0][i], 0);
+#pragma unroll
+  for (int i = 0; i < NW; ++i) put(smem, w_off[i], gw[0][i], 0);
+  __syncthreads();
+  for (int s = 0; s < ns; s += 2) {
+    step(s, 1);
+    if (s + 1 < ns) step(s + 1, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (i >= M) continue;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+      const int n = n0 + 32 * t + r;
+      if (n < N) C[(size_t)i * ldc + n] = acc[t][q];
+    }
+  }
+}
+
 #define CK(x)                                                                  \
   do {                                                                         \
     hipError_t e_ = (x);                                                       \
@@ -462,13 +634,15 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&dWp, hWp.size() * 2));
   CK(hipMemcpy(dWp, hWp.data(), hWp.size() * 2, hipMemcpyHostToDevice));
   unsigned long long* dT;
-  CK(hipMalloc(&dT, (size_t)ntm * ntn * 4 * 6 * 8));
+  CK(hipMalloc(&dT, (size_t)ntm * ntn * 4 * 8 * 8));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const bool use_v2 = getenv("V2") != nullptr;
+  const bool use_v2 = getenv("V2") != nullptr, use_v3 = getenv("V3") != nullptr;
   auto launch = [&]() {
-    if (use_v2)
+    if (use_v3)
+      hipLaunchKernelGGL(nt_v3<NACC>, dim3(ntm * ntn), dim3(256), 0, 0, dA, ld, dW, ld, dC, ld, M, N, K, ntn);
+    else if (use_v2)
       hipLaunchKernelGGL(nt_v2<NACC>, dim3(ntm * ntn), dim3(256), 0, 0, dA, ld, dC, ld, M, N, K, ntn,
                          (const u32x4*)dWp, wp_rows, wp_ld8);
     else
@@ -490,13 +664,13 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
 #ifdef TRACE
   {
-    std::vector<unsigned long long> hT((size_t)ntm * ntn * 4 * 6);
+    std::vector<unsigned long long> hT((size_t)ntm * ntn * 4 * 8);
     CK(hipMemcpy(hT.data(), dT, hT.size() * 8, hipMemcpyDeviceToHost));
-    double ph[6] = {0, 0, 0, 0, 0, 0};
+    double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t w = 0; w < (size_t)ntm * ntn * 4; ++w)
-      for (int i = 0; i < 6; ++i) ph[i] += hT[w * 6 + i];
-    const char* nm[6] = {"prologue", "frag reads + mfma issue", "barrier 1", "wait global + split + lds store", "barrier 2", "epilogue"};
-    for (int i = 0; i < 6; ++i) printf("  %-34s %9.0f cycles per wave (whole block life)\n", nm[i], ph[i] / (ntm * ntn * 4.0));
+      for (int i = 0; i < 8; ++i) ph[i] += hT[w * 8 + i];
+    const char* nm[8] = {"prologue", "frag reads + mfma issue", "barrier 1", "split + lds store issue", "barrier 2", "epilogue", "wait for global values", "wait for lds stores"};
+    for (int i = 0; i < 8; ++i) printf("  %-34s %9.0f cycles per wave (whole block life)\n", nm[i], ph[i] / (ntm * ntn * 4.0));
   }
 #endif
   // accuracy against fp64 on a sample of rows, beside a plain fp32 fma chain

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 
 # entry point (the name bench.py's kernel timer files a call under) -> kernels it launches; a call runs exactly
 # one of the kernels before "|" (they count the calls), and possibly the ones after it
-ENTRY = [("gemm_nt", ("gemm_nt_kernel", "gemm_nt_small_kernel", "gemm_nt_pair_kernel", "gemm_nt_small_pair_kernel",
+ENTRY = [("gemm_nt", ("gemm_nt_kernel", "gemm_nt_split_kernel", "gemm_nt_small_kernel", "gemm_nt_pair_kernel", "gemm_nt_small_pair_kernel",
                       "gru_update_kernel", "gru_update_small_kernel", "|")),
          ("gemm_tn", ("gemm_tn_kernel", "|", "slab_reduce_kernel")),
          ("csr_gather_sum", ("csr_gather_sum_kernel",)), ("gru_gate_gather", ("gru_gate_gather_kernel",)),

@@ -25,8 +25,8 @@ if [ $WHAT = pmc ] || [ $WHAT = all ]; then
     timeout -s KILL 240 rocprofv3 --pmc $CNT --output-format csv -d $D -- python3 $R/bench.py --mode $MODE --batch $BATCH --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-fresh-holders > $D/bench.json 2> $D/bench.err || { tail -5 $D/bench.err; exit 1; }
   done
   cd $R
-  python3 scratch/pmc_summarise.py traffic $OUT $MODE $BATCH 3 gpurun_out/r03_pmc_traffic.json || exit 1
-  python3 scratch/pmc_summarise.py sq $OUT $MODE $BATCH 3 gpurun_out/r03_sq_counters.json || exit 1
+  python3 scratch/pmc_summarise.py traffic $OUT $MODE $BATCH 7 gpurun_out/r03_pmc_traffic.json || exit 1
+  python3 scratch/pmc_summarise.py sq $OUT $MODE $BATCH 7 gpurun_out/r03_sq_counters.json || exit 1
   # the counter CSVs are large: keep the summaries only
   rm -rf $OUT/pmc_FETCH_SIZE/*/ $OUT/pmc_WRITE_SIZE/*/ $OUT/pmc_SQ/*/
 fi

@@ -111,6 +111,44 @@ def test_end_to_end_gradients_match_oracle(seed, B, atoms):
         assert f < (1e-3 if name.startswith("jtmpn.") else RTOL), (name, f)
 
 
+def test_graph_encoder_on_split_products_matches_fp64_oracle():
+    """A batch large enough for the graph encoder's products to take their large-batch form (13 000 bond rows:
+    jtvae_gemm_nt above 10 000 rows and jtvae_gemm_tn above 4 096 rows run on the bf16 matrix instruction with
+    operands split into three bf16 parts), against the oracle's op sequence in fp64: the same bounds as the fp32
+    instruction meets on small batches, and the fp32 form beside it on the same batch."""
+    from common import projection
+    from fast_jtnn_hip import _capi, synthetic, tensorize as T
+
+    class G:
+        pass
+    g = G()
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = 31, 160, 450, 56, 20, 3, 385, 0.05
+    trees = synthetic.make_batch(g.seed, g.B, vocab_size=g.V, mean_atoms=40.0)
+    mp = T.mpn_tensorize([t.mol for t in trees])
+    assert mp[1].shape[0] > 10000
+    hip = make_hip_model(g, "cuda")
+    o64 = make_oracle(g).double()
+    mv64 = o64.mpn(mp[0].double(), mp[1].double(), *mp[2:])
+    R = projection(mv64.shape, 3)
+    (mv64 * R.double()).sum().backward()
+    ref = {n: p.grad.detach().numpy() for n, p in o64.mpn.named_parameters()}
+    err = {}
+    for split in (True, False):
+        was = _capi.set_split_products(split)
+        try:
+            hip.zero_grad(set_to_none=True)
+            mv = hip.mpn(*mp)
+            (mv * R.cuda()).sum().backward()
+            torch.cuda.synchronize()
+        finally:
+            _capi.set_split_products(was)
+        assert rel_err(mv.detach().cpu().numpy(), mv64.detach().numpy()) < 2e-6
+        err[split] = {n: fro_err(p.grad.cpu().numpy(), ref[n]) for n, p in hip.mpn.named_parameters()}
+        for n, e in err[split].items():
+            assert e < 1e-5, (split, n, e)
+    assert any(err[True][n] != err[False][n] for n in err[True])  # two forms ran
+
+
 def test_component_gradients_match_fp64_oracle():
     """Each module alone, fed bit-identical inputs and upstream gradients, against the oracle's
     op sequence run in fp64: what is left is the kernels' own rounding."""
