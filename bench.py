@@ -542,6 +542,16 @@ def main():
         out["roofline"]["traffic_source"] = ("replayed from %s (rocprofv3 --pmc passes over this command; kernel "
                                              "sources and launch counts match)" % os.path.relpath(PMC_TRAFFIC_FILE, ROOT)
                                              if dom["traffic"] is not None else None)
+        if dom["bound"] == "mfma":
+            from fast_jtnn_hip import _capi as K
+            split = bool(K.lib.jtvae_set_split_products(-1))
+            out["roofline"]["peak_what"] = (
+                "dense peak of the fp32 matrix instruction, the form every product below ~10 000 rows runs in"
+                + ("; the larger launches run as three-way bf16 splits of the fp32 operands on the bf16 matrix "
+                   "instruction with fp32 accumulation (fp32-accurate; ceiling 2500 / 6 = 417 TFLOP/s "
+                   "fp32-equivalent, 323 measured with nothing but matrix instructions), so a launch class in "
+                   "by_rows can exceed this figure" if split else ""))
+            out["roofline"]["large_products"] = "split-bf16" if split else "fp32"
         out["kernels"] = kernels
         out["launches_per_step"] = sum(k["launches"] for k in kernels)
         # HIP-event pairs around back-to-back launches overlap by the event latency, so this sum can exceed

@@ -111,18 +111,23 @@ def test_end_to_end_gradients_match_oracle(seed, B, atoms):
         assert f < (1e-3 if name.startswith("jtmpn.") else RTOL), (name, f)
 
 
-def test_graph_encoder_on_split_products_matches_fp64_oracle():
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_graph_encoder_on_split_products_matches_fp64_oracle(seed):
     """A batch large enough for the graph encoder's products to take their large-batch form (13 000 bond rows:
     jtvae_gemm_nt above 10 000 rows and jtvae_gemm_tn above 4 096 rows run on the bf16 matrix instruction with
-    operands split into three bf16 parts), against the oracle's op sequence in fp64: the same bounds as the fp32
-    instruction meets on small batches, and the fp32 form beside it on the same batch."""
+    operands split into three bf16 parts), against the oracle's op sequence in fp64, the fp32 form beside it on
+    the same batch.  Output: 2e-6 in either form.  Gradients: within 1e-6 of the fp64 run's (3-6e-7 measured, either
+    form) unless a ReLU unit sits within rounding of its switching point, which at this size (6 million units)
+    happens to one form or the other depending on the batch: seed 31 switches a unit in the fp32 form (its W_i
+    gradient 2.0e-4 off, the split form's 5e-7), seed 32 one in the split form (6.5e-4 against 3e-7), seed 33 none
+    (all eight tensors below 6e-7).  Hence: the untouched tensors (W_o) below 2e-6, every tensor below 2e-3."""
     from common import projection
     from fast_jtnn_hip import _capi, synthetic, tensorize as T
 
     class G:
         pass
     g = G()
-    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = 31, 160, 450, 56, 20, 3, 385, 0.05
+    g.seed, g.B, g.H, g.L, g.dT, g.dG, g.V, g.bias_scale = seed, 160, 450, 56, 20, 3, 385, 0.05
     trees = synthetic.make_batch(g.seed, g.B, vocab_size=g.V, mean_atoms=40.0)
     mp = T.mpn_tensorize([t.mol for t in trees])
     assert mp[1].shape[0] > 10000
@@ -145,7 +150,7 @@ def test_graph_encoder_on_split_products_matches_fp64_oracle():
         assert rel_err(mv.detach().cpu().numpy(), mv64.detach().numpy()) < 2e-6
         err[split] = {n: fro_err(p.grad.cpu().numpy(), ref[n]) for n, p in hip.mpn.named_parameters()}
         for n, e in err[split].items():
-            assert e < 1e-5, (split, n, e)
+            assert e < (2e-6 if n.startswith("W_o") else 2e-3), (split, n, e)
     assert any(err[True][n] != err[False][n] for n in err[True])  # two forms ran
 
 
