@@ -229,11 +229,15 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
         bf16x8 b1 = *reinterpret_cast<const bf16x8*>(smem + boff);
         bf16x8 b2 = *reinterpret_cast<const bf16x8*>(smem + ROWS * 64 + boff);
         bf16x8 b3 = *reinterpret_cast<const bf16x8*>(smem + 2 * ROWS * 64 + boff);
+#if !defined(ONE_MFMA) && !defined(THREE_MFMA)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+#endif
+#if !defined(ONE_MFMA)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+#endif
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
       }
     }
@@ -578,6 +582,132 @@ __global__ __launch_bounds__(256, 3) void nt_v3(const float* __restrict__ A, int
   }
 }
 
+// v4: A goes through LDS as fp32 (one 16-byte store per staged float4, no vector work in the staging phase) and is
+// split in registers after the fragment read - every wave reads only its own 32 rows, so each element is split
+// once per block as before; W arrives pre-split (three bf16 planes in global memory, zero padded) and is copied
+// to LDS as it is.  34 KB of LDS per block.
+template <int NACC>
+__global__ __launch_bounds__(256, 3) void nt_v4(const float* __restrict__ A, int lda, float* __restrict__ C, int ldc,
+                                                int M, int N, int K, int n_tiles_n, const u32x4* __restrict__ Wp,
+                                                int wp_rows, int wp_ld8) {
+  constexpr int BN = 32 * NACC;
+  constexpr int ABYTES = BM * 128;           // fp32 A tile, 128-byte rows, 16-byte slots XORed with (row >> 1) & 7
+  constexpr int WPLANE = BN * 64;
+  constexpr int WCH = 3 * BN * 4, WPT = (WCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ABYTES + 3 * WPLANE];
+  unsigned char* wl = smem + ABYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (tile / n_tiles_n) * BM, n0 = (tile % n_tiles_n) * BN;
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc[NACC];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  const int srow = tid >> 3, sc4 = tid & 7;
+  float4 ra[BM / 32];
+  u32x4 rw[WPT];
+  const float* a_row[BM / 32];
+#pragma unroll
+  for (int i = 0; i < BM / 32; ++i) a_row[i] = A + (size_t)min(m0 + srow + 32 * i, M - 1) * lda;
+  const int nk = (K + BK - 1) / BK;
+  auto load_tiles = [&](int kt) {
+    const int k = kt * BK + 4 * sc4;
+    const int kc = k + 3 < lda ? k : 0;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) ra[i] = *reinterpret_cast<const float4*>(a_row[i] + kc);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = min(tid + 256 * i, WCH - 1);
+      const int plane = c / (BN * 4), rc = c % (BN * 4), row = rc >> 2, ch = rc & 3;
+      rw[i] = Wp[((size_t)plane * wp_rows + n0 + row) * wp_ld8 + kt * 4 + ch];
+    }
+  };
+  auto store_tiles = [&](int kt) {
+    const bool tail = kt * BK + BK > K;
+#pragma unroll
+    for (int i = 0; i < BM / 32; ++i) {
+      float4 v = ra[i];
+      if (tail) {  // what lies past K may be anything (also NaN): W's zeros there do not protect against it
+        const int k = kt * BK + 4 * sc4;
+        v.x = k + 0 < K ? v.x : 0.f;
+        v.y = k + 1 < K ? v.y : 0.f;
+        v.z = k + 2 < K ? v.z : 0.f;
+        v.w = k + 3 < K ? v.w : 0.f;
+      }
+      const int row = srow + 32 * i;
+      *reinterpret_cast<float4*>(smem + row * 128 + 16 * (sc4 ^ ((row >> 1) & 7))) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = min(tid + 256 * i, WCH - 1);
+      const int plane = c / (BN * 4), rc = c % (BN * 4), row = rc >> 2, ch = rc & 3;
+      *reinterpret_cast<u32x4*>(wl + plane * WPLANE + row * 64 + 16 * ((ch + (row >> 2)) & 3)) = rw[i];
+    }
+  };
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+  const int arow = wave * 32 + r;
+  const int asw = (arow >> 1) & 7;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles(kt + 1);
+    const int ks_end = min(2, (K - kt * BK + 15) >> 4);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s >= ks_end) break;
+      // lane (r, h): k = 16 s + 8 h .. + 8 of its row: slots 4 s + 2 h and + 1
+      const int sl = 4 * s + 2 * h;
+      const float4 x0 = *reinterpret_cast<const float4*>(smem + arow * 128 + 16 * (sl ^ asw));
+      const float4 x1 = *reinterpret_cast<const float4*>(smem + arow * 128 + 16 * ((sl + 1) ^ asw));
+      unsigned p[3][4];
+      split3(x0.x, x0.y, p[0][0], p[1][0], p[2][0]);
+      split3(x0.z, x0.w, p[0][1], p[1][1], p[2][1]);
+      split3(x1.x, x1.y, p[0][2], p[1][2], p[2][2]);
+      split3(x1.z, x1.w, p[0][3], p[1][3], p[2][3]);
+      const u32x4 q1 = {p[0][0], p[0][1], p[0][2], p[0][3]};
+      const u32x4 q2 = {p[1][0], p[1][1], p[1][2], p[1][3]};
+      const u32x4 q3 = {p[2][0], p[2][1], p[2][2], p[2][3]};
+      const bf16x8 a1 = __builtin_bit_cast(bf16x8, q1), a2 = __builtin_bit_cast(bf16x8, q2),
+                   a3 = __builtin_bit_cast(bf16x8, q3);
+      const int slot = 2 * s + h;
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) {
+        const int brow = 32 * t + r;
+        const int boff = brow * 64 + 16 * ((slot + (brow >> 2)) & 3);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wl + boff);
+        const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(wl + WPLANE + boff);
+        const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(wl + 2 * WPLANE + boff);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      store_tiles(kt + 1);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = m0 + wave * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (i >= M) continue;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+      const int n = n0 + 32 * t + r;
+      if (n < N) C[(size_t)i * ldc + n] = acc[t][q];
+    }
+  }
+}
+
 #define CK(x)                                                                  \
   do {                                                                         \
     hipError_t e_ = (x);                                                       \
@@ -639,8 +769,12 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const bool use_v2 = getenv("V2") != nullptr, use_v3 = getenv("V3") != nullptr;
+  const bool use_v4 = getenv("V4") != nullptr;
   auto launch = [&]() {
-    if (use_v3)
+    if (use_v4)
+      hipLaunchKernelGGL(nt_v4<NACC>, dim3(ntm * ntn), dim3(256), 0, 0, dA, ld, dC, ld, M, N, K, ntn,
+                         (const u32x4*)dWp, wp_rows, wp_ld8);
+    else if (use_v3)
       hipLaunchKernelGGL(nt_v3<NACC>, dim3(ntm * ntn), dim3(256), 0, 0, dA, ld, dW, ld, dC, ld, M, N, K, ntn);
     else if (use_v2)
       hipLaunchKernelGGL(nt_v2<NACC>, dim3(ntm * ntn), dim3(256), 0, 0, dA, ld, dC, ld, M, N, K, ntn,
