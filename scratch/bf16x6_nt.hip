@@ -165,7 +165,37 @@ __global__ __launch_bounds__(256, 3) void nt_bf16x6(const float* __restrict__ A,
   const int r = lane & 31, h = lane >> 5;
   const int arow = wave * 32 + r;
   PH(0);
-#ifdef LOOKAHEAD
+#ifdef INTERLEAVE
+  // no matrix instruction depends on the one issued just before it: the six terms go round the accumulators
+  auto mfma_tile = [&](int kt) {
+    const int ks_end = min(2, (K - kt * BK + 15) >> 4);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s >= ks_end) break;
+      const int slot = 2 * s + h;
+      const int aoff = arow * 64 + 16 * ((slot + (arow >> 2)) & 3);
+      bf16x8 a[3], b[NACC][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(smem + p * ROWS * 64 + aoff);
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) {
+        const int brow = BM + 32 * t + r;
+        const int boff = brow * 64 + 16 * ((slot + (brow >> 2)) & 3);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[t][p] = *reinterpret_cast<const bf16x8*>(smem + p * ROWS * 64 + boff);
+      }
+      constexpr int IA[6] = {2, 0, 1, 1, 0, 0}, IB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int t = 0; t < NACC; ++t)
+        {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[IA[j]], b[t][IB[j]], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+  };
+#elif defined(LOOKAHEAD)
   // fragments one group of six matrix instructions ahead: A of both k steps up front, B of group g + 1 requested
   // before the instructions of group g are issued
   auto mfma_tile = [&](int kt) {
