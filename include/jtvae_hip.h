@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 15
+#define JTVAE_ABI_VERSION 16
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -306,6 +306,58 @@ int jtvae_gru_bwd_dh(const float* du, const float* UrT, int32_t ldw, const float
                      const int32_t* rows, int32_t n_rows, const float* z, const float* p, const float* s,
                      size_t slab_stride, int32_t t_iter, const int32_t* sf, float* dzpre, float* dppre, float* ds,
                      int32_t H, int32_t ld, int32_t pad_row, void* stream);
+
+/* ---- the graph message passing network, one host call per pass ---------------------------------- */
+
+/* MPN.forward / JTMPN.forward (fast_jtnn/mpn.py:81-108, fast_jtnn/jtmpn.py:81-111) on prepared inputs: float
+ * feature rows fbonds [n_bonds, ld_fb] / fatoms [n_atoms, ld_fa], the weight blocks W_i [H, ld_wi], W_h [H, ld],
+ * W_o[:, :fa_dim] [H, ld_woa], W_o[:, fa_dim:] [H, ld], bias bo [H], the CSR forms of bgraph / agraph (ids below
+ * n_tree are rows of `tree`, the rest bond rows; tree = NULL, n_tree = 0 for MPN) and the segment table.  msg / nei
+ * are HOST arrays of device row buffers [n_bonds, ld]: msg[0] receives binput, msg[i] the messages after iteration
+ * i (depth entries), nei[i-1] the neighbour sums of iteration i (depth - 1 entries); a caller that keeps nothing for
+ * a backward pass may let nei entries alias each other and msg[i] alias msg[i-2].  anei, ah: [n_atoms, ld]; out:
+ * [n_seg, ld].  Issues jtvae_gemm_nt, (jtvae_csr_gather_sum, jtvae_gemm_nt) x (depth - 1), jtvae_csr_gather_sum,
+ * jtvae_gemm_nt x 2, jtvae_segment_mean: bit-identical to issuing them one by one. */
+typedef struct jtvae_mpn_fwd {
+  const float* fbonds;
+  const float* fatoms;
+  const float *Wi, *Wh, *Woa, *Woh, *bo;
+  const float* tree;
+  const int32_t *b_rowptr, *b_col, *a_rowptr, *a_col;
+  const int32_t* seg;
+  float* const* msg;
+  float* const* nei;
+  float *anei, *ah, *out;
+  int32_t ld_fb, ld_fa, ld_wi, ld_woa;
+  int32_t n_tree, n_bonds, n_atoms, n_seg, fb_dim, fa_dim, H, ld, depth;
+} jtvae_mpn_fwd_t;
+int jtvae_graph_mpn_forward(const jtvae_mpn_fwd_t* args, void* stream);
+
+/* The matching backward pass (autograd of the same lines): dout [n_seg, ld] in; dW_i [H, ld_dwi], dW_h [H, H],
+ * dW_o [H, ld_dwo] (atom columns first), db_o [H] and, with tree rows, dtree [n_tree, ld] out.  msg, nei, anei, ah:
+ * what the forward call left; WhT / WohT: the transposed weight blocks [H, ld]; at_* / bt_*: transposed CSR of
+ * agraph / bgraph over (tree rows | bond rows); seg_of: segment of every atom.  Scratch by the caller: dpre_o, danei
+ * [n_atoms, ld]; dpre, dnei, dbinput [n_bonds, ld]; workspace of at least the largest
+ * jtvae_gemm_tn_workspace_bytes among the four weight-gradient products.  Bit-identical to the launch-by-launch
+ * form. */
+typedef struct jtvae_mpn_bwd {
+  const float* dout;
+  const float* fbonds;
+  const float* fatoms;
+  const float *WhT, *WohT;
+  float* const* msg;
+  float* const* nei;
+  const float *anei, *ah;
+  const int32_t *at_rowptr, *at_col, *bt_rowptr, *bt_col;
+  const int32_t *seg, *seg_of;
+  float *dpre_o, *danei, *dpre, *dnei, *dbinput;
+  float *dW_i, *dW_h, *dW_o, *db_o, *dtree;
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t ld_fb, ld_fa, ld_dwi, ld_dwo;
+  int32_t n_tree, n_bonds, n_atoms, n_seg, fb_dim, fa_dim, H, ld, depth;
+} jtvae_mpn_bwd_t;
+int jtvae_graph_mpn_backward(const jtvae_mpn_bwd_t* args, void* stream);
 
 /* ---- whole level sweeps of the compute-once schedule, one host call each ---------------------- */
 

@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("JTVAE_HIP_LIB") or os.path.join(_HERE, "libjtvae_hip.
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class Epilogue(C.Structure):
@@ -97,6 +97,24 @@ class PackItem(C.Structure):
 
 
 
+
+class MpnFwdArgs(C.Structure):  # jtvae_mpn_fwd_t
+    _fields_ = ([(n, C.c_void_p) for n in ("fbonds", "fatoms", "Wi", "Wh", "Woa", "Woh", "bo", "tree", "b_rowptr",
+                                           "b_col", "a_rowptr", "a_col", "seg", "msg", "nei", "anei", "ah", "out")] +
+                [(n, C.c_int32) for n in ("ld_fb", "ld_fa", "ld_wi", "ld_woa", "n_tree", "n_bonds", "n_atoms", "n_seg",
+                                          "fb_dim", "fa_dim", "H", "ld", "depth")])
+
+
+class MpnBwdArgs(C.Structure):  # jtvae_mpn_bwd_t
+    _fields_ = ([(n, C.c_void_p) for n in ("dout", "fbonds", "fatoms", "WhT", "WohT", "msg", "nei", "anei", "ah",
+                                           "at_rowptr", "at_col", "bt_rowptr", "bt_col", "seg", "seg_of", "dpre_o",
+                                           "danei", "dpre", "dnei", "dbinput", "dW_i", "dW_h", "dW_o", "db_o", "dtree",
+                                           "workspace")] +
+                [("workspace_bytes", C.c_size_t)] +
+                [(n, C.c_int32) for n in ("ld_fb", "ld_fa", "ld_dwi", "ld_dwo", "n_tree", "n_bonds", "n_atoms",
+                                          "n_seg", "fb_dim", "fa_dim", "H", "ld", "depth")])
+
+
 class GraphSetC(C.Structure):
     _fields_ = [("n_graphs", C.c_int64), ("atom_ptr", C.c_void_p), ("bond_ptr", C.c_void_p), ("atom_feats", C.c_void_p),
                 ("bonds", C.c_void_p), ("bond_feats", C.c_void_p), ("atom_nid", C.c_void_p), ("atom_fdim", C.c_int32),
@@ -159,6 +177,8 @@ SIGNATURES = {
     "jtvae_set_split_products": (C.c_int, [C.c_int]),
     "jtvae_tree_gru_forward": (C.c_int, [_vp, _vp]),
     "jtvae_tree_gru_backward": (C.c_int, [_vp, _vp]),
+    "jtvae_graph_mpn_forward": (C.c_int, [_vp, _vp]),
+    "jtvae_graph_mpn_backward": (C.c_int, [_vp, _vp]),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "jtvae_prep_features_to_u8": (C.c_int, [_vp, _i64, _vp, C.POINTER(C.c_int32)]),
     "jtvae_widen_u8_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
@@ -500,6 +520,23 @@ def tree_gru_forward(args):
 
 def tree_gru_backward(args):
     check(lib.jtvae_tree_gru_backward(C.byref(args), stream_ptr()), "tree_gru_backward")
+
+
+def pointer_array(tensors):
+    """Host array of the device addresses of a sequence of tensors."""
+    return (C.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
+
+
+def graph_mpn_forward(args):
+    check(lib.jtvae_graph_mpn_forward(C.byref(args), stream_ptr()), "graph_mpn_forward")
+
+
+def graph_mpn_backward(args):
+    check(lib.jtvae_graph_mpn_backward(C.byref(args), stream_ptr()), "graph_mpn_backward")
+
+
+def gemm_tn_workspace_bytes(M, N, Kd):
+    return int(lib.jtvae_gemm_tn_workspace_bytes(M, N, Kd))
 
 
 def gru_bwd_pointwise(dh, z, p, s, slab_stride, t_iter, sf, rows, n_rows, dzpre, dppre, ds, H, ld, pad_row=0):

@@ -21,6 +21,7 @@ gathers read from ``[tree messages ; bond messages]``.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from collections import OrderedDict
 
@@ -175,42 +176,68 @@ class _GraphMPNFunction(torch.autograd.Function):
                 K.csr_gather_sum(out.data_ptr(), msg.data_ptr(), NB, None, csr.rowptr.data_ptr(),
                                  csr.col.data_ptr(), n_rows, H, ld, nnz=csr.nnz, relu_src=pre_act)
 
-        binput = K.rows(NB, ld, dev)
-        # binput = W_i fbonds; message 0 = relu(binput) is never stored: its readers take the ReLU themselves
-        # and the backward mask (message > 0) is binput > 0                                    (mpn.py:87-88)
-        if oh_b:
-            K.onehot_linear(P.fbonds_u8.data_ptr(), NB, fb_dim, Wi.data_ptr(), Wi.stride(0), None, binput.data_ptr(), ld, H)
-        else:
-            fbonds = P.float_rows("fbonds")
-            K.gemm_nt(fbonds.data_ptr(), fbonds.stride(0), Wi.data_ptr(), Wi.stride(0), binput.data_ptr(), ld,
-                      NB, H, fb_dim)
-        msgs = [binput]
-        neis = []
-        for _ in range(depth - 1):  # mpn.py:90-94
-            nei = K.rows(NB, ld, dev)
-            gather(nei, msgs[-1], P.bcsr, NB, msgs[-1] is binput)
-            new = K.rows(NB, ld, dev)
-            K.gemm_nt(nei.data_ptr(), ld, Wh.data_ptr(), ld, new.data_ptr(), ld, NB, H, H,
-                      add=binput.data_ptr(), ld_add=ld, act=K.ACT_RELU)
-            neis.append(nei)
-            msgs.append(new)
+        one_call = K.sweeps_enabled() and not (oh_a or oh_b)
+        if one_call:
+            # the whole pass as ONE host call (jtvae_graph_mpn_forward): the same launches in the same order
+            fbonds, fatoms = P.float_rows("fbonds"), P.float_rows("fatoms")
+            binput = K.rows(NB, ld, dev)
+            msgs = [binput] + [K.rows(NB, ld, dev) for _ in range(depth - 1)]
+            if train:
+                neis = [K.rows(NB, ld, dev) for _ in range(depth - 1)]
+                nei_bufs = neis
+            else:  # nothing is kept: one neighbour-sum buffer serves every iteration
+                neis = []
+                nei_bufs = [K.rows(NB, ld, dev)] * (depth - 1) if depth > 1 else []
+            anei, ah, out = K.rows(NA, ld, dev), K.rows(NA, ld, dev), K.rows(P.n_seg, ld, dev)
+            msg_arr, nei_arr = K.pointer_array(msgs), K.pointer_array(nei_bufs)
+            a = K.MpnFwdArgs(
+                fbonds=fbonds.data_ptr(), fatoms=fatoms.data_ptr(), Wi=Wi.data_ptr(), Wh=Wh.data_ptr(),
+                Woa=Woa.data_ptr(), Woh=Woh.data_ptr(), bo=W_o_b.detach().data_ptr(), tree=src0,
+                b_rowptr=P.bcsr.rowptr.data_ptr(), b_col=P.bcsr.col.data_ptr(), a_rowptr=P.acsr.rowptr.data_ptr(),
+                a_col=P.acsr.col.data_ptr(), seg=P.seg.data_ptr(), msg=C.cast(msg_arr, C.c_void_p),
+                nei=C.cast(nei_arr, C.c_void_p), anei=anei.data_ptr(), ah=ah.data_ptr(), out=out.data_ptr(),
+                ld_fb=fbonds.stride(0), ld_fa=fatoms.stride(0), ld_wi=Wi.stride(0), ld_woa=Woa.stride(0), n_tree=TM,
+                n_bonds=NB, n_atoms=NA, n_seg=P.n_seg, fb_dim=fb_dim, fa_dim=fa_dim, H=H, ld=ld, depth=depth)
+            K.graph_mpn_forward(a)
             if not train:
                 msgs = msgs[-1:]
-                neis = []
-        anei = K.rows(NA, ld, dev)  # mpn.py:96-99
-        gather(anei, msgs[-1], P.acsr, NA, msgs[-1] is binput)
-        ah = K.rows(NA, ld, dev)
-        if oh_a:
-            K.onehot_linear(P.fatoms_u8.data_ptr(), NA, fa_dim, Woa.data_ptr(), Woa.stride(0),
-                            W_o_b.detach().data_ptr(), ah.data_ptr(), ld, H)
         else:
-            fatoms = P.float_rows("fatoms")
-            K.gemm_nt(fatoms.data_ptr(), fatoms.stride(0), Woa.data_ptr(), Woa.stride(0), ah.data_ptr(), ld,
-                      NA, H, fa_dim, bias=W_o_b.detach().data_ptr())
-        K.gemm_nt(anei.data_ptr(), ld, Woh.data_ptr(), ld, ah.data_ptr(), ld, NA, H, H,
-                  add=ah.data_ptr(), ld_add=ld, act=K.ACT_RELU)
-        out = K.rows(P.n_seg, ld, dev)  # mpn.py:102-107
-        K.segment_mean(out.data_ptr(), ah.data_ptr(), P.seg.data_ptr(), P.n_seg, H, ld, n_rows=NA)
+            binput = K.rows(NB, ld, dev)
+            # binput = W_i fbonds; message 0 = relu(binput) is never stored: its readers take the ReLU themselves
+            # and the backward mask (message > 0) is binput > 0                                    (mpn.py:87-88)
+            if oh_b:
+                K.onehot_linear(P.fbonds_u8.data_ptr(), NB, fb_dim, Wi.data_ptr(), Wi.stride(0), None, binput.data_ptr(), ld, H)
+            else:
+                fbonds = P.float_rows("fbonds")
+                K.gemm_nt(fbonds.data_ptr(), fbonds.stride(0), Wi.data_ptr(), Wi.stride(0), binput.data_ptr(), ld,
+                          NB, H, fb_dim)
+            msgs = [binput]
+            neis = []
+            for _ in range(depth - 1):  # mpn.py:90-94
+                nei = K.rows(NB, ld, dev)
+                gather(nei, msgs[-1], P.bcsr, NB, msgs[-1] is binput)
+                new = K.rows(NB, ld, dev)
+                K.gemm_nt(nei.data_ptr(), ld, Wh.data_ptr(), ld, new.data_ptr(), ld, NB, H, H,
+                          add=binput.data_ptr(), ld_add=ld, act=K.ACT_RELU)
+                neis.append(nei)
+                msgs.append(new)
+                if not train:
+                    msgs = msgs[-1:]
+                    neis = []
+            anei = K.rows(NA, ld, dev)  # mpn.py:96-99
+            gather(anei, msgs[-1], P.acsr, NA, msgs[-1] is binput)
+            ah = K.rows(NA, ld, dev)
+            if oh_a:
+                K.onehot_linear(P.fatoms_u8.data_ptr(), NA, fa_dim, Woa.data_ptr(), Woa.stride(0),
+                                W_o_b.detach().data_ptr(), ah.data_ptr(), ld, H)
+            else:
+                fatoms = P.float_rows("fatoms")
+                K.gemm_nt(fatoms.data_ptr(), fatoms.stride(0), Woa.data_ptr(), Woa.stride(0), ah.data_ptr(), ld,
+                          NA, H, fa_dim, bias=W_o_b.detach().data_ptr())
+            K.gemm_nt(anei.data_ptr(), ld, Woh.data_ptr(), ld, ah.data_ptr(), ld, NA, H, H,
+                      add=ah.data_ptr(), ld_add=ld, act=K.ACT_RELU)
+            out = K.rows(P.n_seg, ld, dev)  # mpn.py:102-107
+            K.segment_mean(out.data_ptr(), ah.data_ptr(), P.seg.data_ptr(), P.n_seg, H, ld, n_rows=NA)
 
         if train:
             P.ensure_transposes()
@@ -237,12 +264,38 @@ class _GraphMPNFunction(torch.autograd.Function):
         dtree = K.rows(TM, ld, dev) if TM else None
 
         dout_p = as_row_buffer(dout, H, ld)
+        w_in = ctx.W_o_shape[1]
+        oh_a, oh_b = ctx.onehot
+        if K.sweeps_enabled() and not (oh_a or oh_b):
+            # the whole pass as ONE host call (jtvae_graph_mpn_backward): the same launches in the same order
+            fbonds, fatoms = P.float_rows("fbonds"), P.float_rows("fatoms")
+            dpre_o, danei = K.rows(NA, ld, dev), K.rows(NA, ld, dev)
+            dpre, dbinput = K.rows(NB, ld, dev), K.rows(NB, ld, dev)
+            dnei = K.rows(NB, ld, dev) if depth > 1 else None
+            ws_bytes = max(K.gemm_tn_workspace_bytes(NA, H, H), K.gemm_tn_workspace_bytes(NA, H, fa_dim),
+                           K.gemm_tn_workspace_bytes(NB, H, H), K.gemm_tn_workspace_bytes(NB, H, fb_dim), 16)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            msg_arr, nei_arr = K.pointer_array(msgs), K.pointer_array(neis)
+            a = K.MpnBwdArgs(
+                dout=dout_p.data_ptr(), fbonds=fbonds.data_ptr(), fatoms=fatoms.data_ptr(), WhT=WhT.data_ptr(),
+                WohT=WohT.data_ptr(), msg=C.cast(msg_arr, C.c_void_p), nei=C.cast(nei_arr, C.c_void_p),
+                anei=anei.data_ptr(), ah=ah.data_ptr(), at_rowptr=P.acsr_t.rowptr.data_ptr(),
+                at_col=P.acsr_t.col.data_ptr(), bt_rowptr=P.bcsr_t.rowptr.data_ptr(), bt_col=P.bcsr_t.col.data_ptr(),
+                seg=P.seg.data_ptr(), seg_of=P.seg_of.data_ptr(), dpre_o=dpre_o.data_ptr(), danei=danei.data_ptr(),
+                dpre=dpre.data_ptr(), dnei=None if dnei is None else dnei.data_ptr(), dbinput=dbinput.data_ptr(),
+                dW_i=dW_i.data_ptr(), dW_h=dW_h.data_ptr(), dW_o=dW_o.data_ptr(), db_o=db_o.data_ptr(),
+                dtree=None if dtree is None else dtree.data_ptr(), workspace=ws.data_ptr(), workspace_bytes=ws_bytes,
+                ld_fb=fbonds.stride(0), ld_fa=fatoms.stride(0), ld_dwi=ctx.W_i_shape[1], ld_dwo=w_in, n_tree=TM,
+                n_bonds=NB, n_atoms=NA, n_seg=P.n_seg, fb_dim=fb_dim, fa_dim=fa_dim, H=H, ld=ld, depth=depth)
+            K.graph_mpn_backward(a)
+            dtree_out = None
+            if TM and ctx.needs_input_grad[4]:
+                dtree_out = dense_view(dtree, H)
+            return dW_i, dW_h, dW_o, db_o, dtree_out, None, None, None
         # through the mean readout and the ReLU of W_o                    (mpn.py:99-105)
         dpre_o = K.rows(NA, ld, dev)
         K.segment_mean_bwd(dpre_o.data_ptr(), dout_p.data_ptr(), ah.data_ptr(), P.seg.data_ptr(),
                            P.seg_of.data_ptr(), NA, H, ld, n_seg=P.n_seg)
-        w_in = ctx.W_o_shape[1]
-        oh_a, oh_b = ctx.onehot
         if oh_a:
             K.onehot_linear_bwd(P.fatoms_u8.data_ptr(), NA, fa_dim, dpre_o.data_ptr(), ld, H, dW_o.data_ptr(), w_in,
                                 False, dev)

@@ -586,9 +586,10 @@ def test_one_deep_tree_in_a_batch_keeps_the_batch_on_the_compute_once_schedule()
 
 
 def test_one_call_level_sweeps_are_bitwise_the_launch_by_launch_form():
-    """jtvae_tree_gru_forward / _backward issue the launches of the level loop in the same order: outputs and
-    every gradient are bit-identical to the launch-by-launch form (which is what runs while launches are being
-    timed), with the gradient reaching all messages (through JTMPN) and with it reaching the roots only."""
+    """jtvae_tree_gru_forward / _backward issue the launches of the level loop in the same order, and
+    jtvae_graph_mpn_forward / _backward those of the graph encoder and the candidate encoder: outputs and every
+    gradient are bit-identical to the launch-by-launch form (which is what runs while launches are being timed),
+    with the gradient reaching all messages (through JTMPN) and with it reaching the roots only."""
     from fast_jtnn_hip import _capi as K
 
     g = Golden(CASES[2])
@@ -615,9 +616,11 @@ def test_one_call_level_sweeps_are_bitwise_the_launch_by_launch_form():
             assert not K.sweeps_enabled()
             out_b, grad_b = run(with_cands)
         assert any(r[0] == "gru_gate_gather" for r in kt.records)  # the loop form really ran
+        assert any(r[0] == "segment_mean" for r in kt.records)  # ... of the graph encoders too
         for x, y in zip(out_a, out_b):
             assert torch.equal(x, y)
         assert set(grad_a) == set(grad_b) and any(n.startswith("jtnn.") for n in grad_a)
+        assert any(n.startswith("mpn.") for n in grad_a) and (not with_cands or any(n.startswith("jtmpn.") for n in grad_a))
         for n in grad_a:
             assert torch.equal(grad_a[n], grad_b[n]), n
     with torch.no_grad():  # inference form (no saved state)
