@@ -773,3 +773,23 @@ def test_weight_gradient_in_split_form_is_fp32_accurate(K, M):
         assert e < 2e-6 and eb < 1e-6 and ep < 2e-6, (on, e, eb, ep)
         rms[on] = e
     assert rms[True] < 2.5 * rms[False]
+
+
+@pytest.mark.gpu
+def test_graph_mpn_sweeps_reject_bad_arguments(K):
+    """jtvae_graph_mpn_forward / _backward check their argument blocks on the host before any launch."""
+    import ctypes as C
+    assert K.lib.jtvae_graph_mpn_forward(None, None) == -1  # JTVAE_E_NULL
+    assert K.lib.jtvae_graph_mpn_backward(None, None) == -1
+    a = K.MpnFwdArgs()
+    a.depth, a.H, a.ld = 0, 450, 452
+    assert K.lib.jtvae_graph_mpn_forward(C.byref(a), None) == -2  # JTVAE_E_SHAPE: depth < 1
+    a.depth, a.H, a.ld = 3, 450, 448
+    assert K.lib.jtvae_graph_mpn_forward(C.byref(a), None) == -2  # ld < H
+    a.ld = 452
+    assert K.lib.jtvae_graph_mpn_forward(C.byref(a), None) == -1  # no message buffers
+    b = K.MpnBwdArgs()
+    b.depth, b.H, b.ld = 3, 450, 452
+    assert K.lib.jtvae_graph_mpn_backward(C.byref(b), None) == -1
+    b.n_bonds = -1
+    assert K.lib.jtvae_graph_mpn_backward(C.byref(b), None) == -2
