@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 16
+#define JTVAE_ABI_VERSION 17
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -98,6 +98,14 @@ const char* jtvae_error_string(int code);
  * JTVAE_SPLIT_BF16=0 sets the initial state.  No counterpart in the reference (torch.nn.Linear picks its own
  * GEMM kernel by size as well). */
 int jtvae_set_split_products(int on);
+
+/* Row count up to which the products issued by the CALLING THREAD take the one-tile-per-block kernels (whole inner
+ * extent in 115 KB of LDS, one memory round trip: the fastest form of a launch that has the GPU to itself); rows < 0
+ * restores the default (512).  Those kernels need a CU to themselves, so a launch that runs beside a large product
+ * of another stream waits until CUs drain; the 128 x 32 tiling (23 KB of LDS, <= 80 registers) it falls back to with
+ * rows = 0 finds room beside three resident blocks of the large products at once.  Returns the previous setting
+ * (-1 = default).  No counterpart in the reference. */
+int jtvae_set_small_tile_rows(int rows);
 
 /* C[M,N] = epilogue(A[M,K] . W[N,K]^T).  Replaces every nn.Linear call on the path:
  * fast_jtnn/mpn.py:87,93,99; fast_jtnn/jtnn_enc.py:33,115,117-118,124;

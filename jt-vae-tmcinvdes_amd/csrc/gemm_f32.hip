@@ -1205,12 +1205,13 @@ inline TnPlan tn_plan(int M, int N, int K, int ones_col, int max_slab = TN_MAX_S
 
 constexpr int SM_MAX_ROWS_DEFAULT = 512;  // above this the tiled kernel fills the chip anyway
 // JTVAE_NT_SMALL_MAX_M overrides it (tests lower it to send small products through the tiled forms)
+thread_local int small_rows_override = -1;  // jtvae_set_small_tile_rows
 int small_max_rows() {
   static const int v = [] {
     const char* e = getenv("JTVAE_NT_SMALL_MAX_M");
     return e ? atoi(e) : SM_MAX_ROWS_DEFAULT;
   }();
-  return v;
+  return small_rows_override >= 0 ? small_rows_override : v;
 }
 #define SM_MAX_ROWS small_max_rows()
 
@@ -1600,6 +1601,12 @@ int jtvae_gemm_tn_static(const float* X, int32_t ldx, const int32_t* x_rows, con
 }
 
 int jtvae_abi_version(void) { return JTVAE_ABI_VERSION; }
+
+int jtvae_set_small_tile_rows(int rows) {
+  const int before = small_rows_override;
+  small_rows_override = rows < 0 ? -1 : rows;
+  return before;
+}
 
 int jtvae_set_split_products(int on) {
   const int before = split_enabled() ? 1 : 0;

@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("JTVAE_HIP_LIB") or os.path.join(_HERE, "libjtvae_hip.
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class Epilogue(C.Structure):
@@ -175,6 +175,7 @@ SIGNATURES = {
     "jtvae_prep_stable_from": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "jtvae_nt_launch_count": (C.c_uint64, []),
     "jtvae_set_split_products": (C.c_int, [C.c_int]),
+    "jtvae_set_small_tile_rows": (C.c_int, [C.c_int]),
     "jtvae_tree_gru_forward": (C.c_int, [_vp, _vp]),
     "jtvae_tree_gru_backward": (C.c_int, [_vp, _vp]),
     "jtvae_graph_mpn_forward": (C.c_int, [_vp, _vp]),
@@ -373,6 +374,20 @@ def gemm_nt(A, lda, W, ldw, Cout, ldc, M, N, K, *, bias=None, add=None, ld_add=0
     _run("gemm_nt", lib.jtvae_gemm_nt, (A, lda, W, ldw, Cout, ldc, M, N, K, C.byref(e), stream_ptr()),
          nbytes=4 * (M * K + N * K + M * N * (1 + extra)), flops=2 * M * N * K,
          tag="M=%d N=%d K=%d mode=%d" % (M, N, K, mode))
+
+
+class small_tile_rows:
+    """Context: products issued by this thread take the one-tile-per-block kernels up to ``rows`` rows only (0: never)."""
+
+    def __init__(self, rows):
+        self.rows = rows
+
+    def __enter__(self):
+        self.before = lib.jtvae_set_small_tile_rows(self.rows) if self.rows is not None else None
+
+    def __exit__(self, *exc):
+        if self.rows is not None:
+            lib.jtvae_set_small_tile_rows(self.before)
 
 
 def set_split_products(on: bool) -> bool:

@@ -27,6 +27,8 @@ What is computed differently from the reference's op sequence (same mathematics)
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -219,6 +221,18 @@ def _keyed_sum(src, pieces, key_csr, n_keys, H, ld, dev):
     return out
 
 
+CROWDED_TILES = os.environ.get("JTVAE_CROWDED_TILES", "1") == "1"
+
+
+def crowded_tiles(crowded):
+    """Row limit of the one-tile-per-block GEMM kernels for launches that run beside another stream's large
+    products (``crowded``): 0, i.e. the 128 x 32 tiling, whose blocks fit on a CU that holds three blocks of a
+    large product, while a one-tile block (115 KB of LDS) waits for a CU to drain - 100 to 250 us on the short
+    levels of a backward sweep.  None (no change) otherwise.  The two tilings sum in different orders: results
+    agree to rounding, not bit for bit."""
+    return 0 if crowded else None
+
+
 def _aside(fn, side_streams, dev, which=0):
     """fn() on side stream ``which`` behind everything the current stream holds so far; returns the event to wait
     for before its results are read (None: there is no such stream and fn ran in place)."""
@@ -245,7 +259,8 @@ class _JTNNEncoderFunction(torch.autograd.Function):
     """forward(E, Wout, bout, Wz, bz, Wr, Ur, bu, Wh, bh) -> (tree_vecs [B,H], messages [NM,H])"""
 
     @staticmethod
-    def forward(ctx, E, Wout, bout, Wz, bz, Wr, Ur_w, bu, Wh, bh, prep, depth, grad_on=True, side_streams=()):
+    def forward(ctx, E, Wout, bout, Wz, bz, Wr, Ur_w, bu, Wh, bh, prep, depth, grad_on=True, side_streams=(),
+                crowded=False):
         dev = E.device
         H = Wr.shape[0]
         ld = K.round_ld(H)
@@ -269,12 +284,15 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         Pz, Pr, Ph, Po = (K.rows(NW, ld, dev) for _ in range(4))
         # the reset-gate table is first read by level 1 of the sweep and the output table after it: with a side
         # stream they leave the chain of dependent launches that the sweep is
-        ev_r = _aside(lambda: K.gemm_nt(Eu.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NW, H, H),
-                      side_streams, dev)
-        ev_o = _aside(lambda: K.gemm_nt(Eu.data_ptr(), ld, Wox.data_ptr(), ld, Po.data_ptr(), ld, NW, H, H,
-                                        bias=bout.detach().data_ptr()), side_streams, dev)
-        K.gemm_nt(Eu.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NW, H, H, bias=bz.detach().data_ptr())
-        K.gemm_nt(Eu.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NW, H, H, bias=bh.detach().data_ptr())
+        # With the graph encoder on another stream, the table products start beside its first large products:
+        # they then take the tiling that finds room on a busy CU (crowded_tiles).
+        with K.small_tile_rows(crowded_tiles(crowded)):
+            ev_r = _aside(lambda: K.gemm_nt(Eu.data_ptr(), ld, Wr_p.data_ptr(), ld, Pr.data_ptr(), ld, NW, H, H),
+                          side_streams, dev)
+            ev_o = _aside(lambda: K.gemm_nt(Eu.data_ptr(), ld, Wox.data_ptr(), ld, Po.data_ptr(), ld, NW, H, H,
+                                            bias=bout.detach().data_ptr()), side_streams, dev)
+            K.gemm_nt(Eu.data_ptr(), ld, Wzx.data_ptr(), ld, Pz.data_ptr(), ld, NW, H, H, bias=bz.detach().data_ptr())
+            K.gemm_nt(Eu.data_ptr(), ld, Whx.data_ptr(), ld, Ph.data_ptr(), ld, NW, H, H, bias=bh.detach().data_ptr())
         _join(ev_r, dev)
         h, st = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p, bu.detach(), Whh,
                                  train)
@@ -293,6 +311,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
             ctx.keep = (Eu, Pr, nsum, tv, Wout, Wz, Wr, Ur_w, Wh)
             ctx.vocab = E.shape[0]
             ctx.side_streams = tuple(side_streams)
+            ctx.crowded = crowded
         return dense_view(tv, H), dense_view(h, H)
 
     @staticmethod
@@ -356,8 +375,10 @@ class _JTNNEncoderFunction(torch.autograd.Function):
                          P.rcsr_t.col.data_ptr(), NM, H, ld, accumulate=dmess is not None, nnz=P.rcsr_t.nnz)
 
         if T >= 1:
-            dz, dp, du, a_r = _TreeGRU.backward(dh, sched, bs, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT,
-                                                WhhT, UrT)
+            # the backward sweep runs beside the graph encoder's backward pass from its first level to its last
+            with K.small_tile_rows(crowded_tiles(ctx.crowded)):
+                dz, dp, du, a_r = _TreeGRU.backward(dh, sched, bs, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT,
+                                                    WhhT, UrT)
 
         def gru_weight_grads():
             # one contraction each over every (iteration, message) pair that carried gradient, operands picked
@@ -387,7 +408,6 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         table_grad("h", dp if swept else None, bs.key_pieces, bs.key, dWh, 2 * H, dbh)
         table_grad("r", a_r if swept else None, P.key_m_pieces, P.key_m, dWr, H, None)
         _join(ev_root, dev)
-        _join(ev_w, dev)
         dPz, dPh, dPo, dPr = (tables[k] for k in "zhor")
         # embedding gradient: dEu = sum_tables dP W[:, :H], scattered to the rows of the words used
         dEu = K.rows(NW, ld, dev)
@@ -401,7 +421,10 @@ class _JTNNEncoderFunction(torch.autograd.Function):
                          P.word_csr_t.col.data_ptr(), V, H, ld, nnz=NW)
         dE = torch.empty((V, H), dtype=torch.float32, device=dev)
         K.copy_rows(dE_p.data_ptr(), ld, dE.data_ptr(), H, V, H)
-        return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None, None, None
+        # the recurrence's weight gradients are not read here: their stream is joined last, so the embedding chain
+        # above runs beside them
+        _join(ev_w, dev)
+        return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None, None, None, None
 
 
 class _MessageGRUFunction(torch.autograd.Function):
@@ -558,6 +581,11 @@ class JTNNEncoder(nn.Module):
     # Streams the backward pass may use beside its own for the independent groups of short launches that follow
     # its level sweep (set by a caller that overlaps the two encoders; empty: everything on one stream).
     side_streams = ()
+    # Whether the short products take the tiling that finds room on a CU busy with another stream's large products
+    # (crowded_tiles).  None: exactly when side streams are set, unless JTVAE_CROWDED_TILES=0; True / False: always /
+    # never, whatever the streams - the setting under which a one-stream and a two-stream pass issue the same
+    # launches and so return the same bits.
+    crowded = None
 
     def forward(self, fnode, fmess, node_graph, mess_graph, scope):
         dev = self.GRU.W_r.weight.device
@@ -597,7 +625,12 @@ class JTNNEncoder(nn.Module):
             return _JTNNEncoderFunction.apply(self.embedding.weight, lin.weight, lin.bias, g.W_z.weight,
                                               g.W_z.bias, g.W_r.weight, g.U_r.weight, g.U_r.bias,
                                               g.W_h.weight, g.W_h.bias, prep, self.depth, torch.is_grad_enabled(),
-                                              self.side_streams)
+                                              self.side_streams, self._crowded())
+
+    def _crowded(self):
+        if self.crowded is None:
+            return CROWDED_TILES and len(self.side_streams) > 0
+        return bool(self.crowded)
 
     @staticmethod
     def tensorize(tree_batch):

@@ -793,3 +793,44 @@ def test_graph_mpn_sweeps_reject_bad_arguments(K):
     assert K.lib.jtvae_graph_mpn_backward(C.byref(b), None) == -1
     b.n_bonds = -1
     assert K.lib.jtvae_graph_mpn_backward(C.byref(b), None) == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [1, 77, 512])
+def test_small_tile_row_limit_picks_the_tiling_and_restores(K, M):
+    """jtvae_set_small_tile_rows: a product of <= 512 rows takes the one-tile kernel by default and the 128 x 32
+    tiling with the limit at 0; both are fp32 fma chains, each within 2e-6 of sum |a w| of the fp64 product.  The setting is per thread, returns the previous value, and -1 restores the default."""
+    import threading
+    import torch
+    H, ld = 450, 452
+    g = torch.Generator(device="cuda").manual_seed(100 + M)
+    A = torch.zeros(M, ld, device="cuda")
+    A[:, :H] = torch.randn(M, H, device="cuda", generator=g)
+    W = torch.zeros(H, ld, device="cuda")
+    W[:, :H] = 0.05 * torch.randn(H, H, device="cuda", generator=g)
+    ref = A[:, :H].double() @ W[:, :H].double().t()
+    mag = A[:, :H].double().abs() @ W[:, :H].double().abs().t()
+
+    def run():
+        C_ = torch.full((M, ld), 3.0, device="cuda")
+        K.gemm_nt(A.data_ptr(), ld, W.data_ptr(), ld, C_.data_ptr(), ld, M, H, H)
+        torch.cuda.synchronize()
+        return C_
+
+    assert K.lib.jtvae_set_small_tile_rows(-1) == -1
+    one_tile = run()
+    with K.small_tile_rows(0):
+        narrow = run()
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(K.lib.jtvae_set_small_tile_rows(-1)))
+        t.start()
+        t.join()
+        assert seen == [-1]  # another thread still has the default
+        with K.small_tile_rows(None):  # None: leave as is
+            assert K.lib.jtvae_set_small_tile_rows(0) == 0
+    assert K.lib.jtvae_set_small_tile_rows(-1) == -1  # restored on exit
+    assert K.lib.jtvae_set_small_tile_rows(-7) == -1  # any negative value is "default"
+    assert torch.equal(run(), one_tile)
+    for C_ in (one_tile, narrow):
+        assert bool((C_[:, H:] == 0).all())
+        assert float(((C_[:, :H].double() - ref).abs() / mag).max()) < 2e-6

@@ -111,14 +111,17 @@ def test_training_step_matches_oracle_on_fresh_batches(seed, B, atoms):
         assert f < (1e-3 if name.startswith("jtmpn.") else 2e-4), (name, f)
 
 
-@pytest.mark.parametrize("B,atoms", [(256, 40.0), (5, 12.0)])
-def test_two_stream_step_is_bitwise_the_one_stream_step(B, atoms):
+@pytest.mark.parametrize("B,atoms,crowded", [(256, 40.0, True), (256, 40.0, False), (5, 12.0, True)])
+def test_two_stream_step_is_bitwise_the_one_stream_step(B, atoms, crowded):
     """The encoders on two overlapping streams (the tree encoder's backward pass spreading its closing groups
     of launches over a helper stream) against everything on one stream: the same launches on the same data, so
     every output and every gradient carries the same bits - checked over several steps, so that a buffer handed
-    back to the allocator while another stream still reads it would show."""
+    back to the allocator while another stream still reads it would show.  The tiling of the tree encoder's short
+    products, which by default follows the stream layout (JTNNEncoder.crowded), is pinned to one setting for both
+    layouts: that choice changes the order of summation, the streams do not."""
     g, x_batch = _seeded_training_problem(77, B, atoms)
     hip = make_hip_model(g, "cuda")
+    hip.jtnn.crowded = crowded
     _, jt, mp, _ = x_batch()
 
     def step(overlap):
@@ -365,3 +368,22 @@ def test_training_cli_from_a_flat_data_set(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.count("Loss:") == 4 and "prop_loss" in out.stdout and "isomer_loss" in out.stdout
     assert "model.epoch-4" in os.listdir(tmp_path / "out")
+
+
+def test_default_tile_policy_of_the_two_stream_step_stays_within_rounding():
+    """By default the tree encoder's short products change tiling when the encoders overlap (JTNNEncoder.crowded
+    = None).  The latent means and variances of the two layouts then differ by summation order only: 1e-5 of the
+    largest entry (fp32 sums of 450 terms, five levels deep)."""
+    g, x_batch = _seeded_training_problem(78, 64, 30.0)
+    hip = make_hip_model(g, "cuda")
+    assert hip.jtnn.crowded is None
+    _, jt, mp, _ = x_batch()
+    out = {}
+    for overlap in (False, True):
+        hip.overlap_streams = overlap
+        with torch.no_grad():
+            mean, logvar = hip.encode_latent(jt, mp)
+        torch.cuda.synchronize()
+        out[overlap] = torch.cat([mean, logvar], 1).double()
+    scale = float(out[False].abs().max())
+    assert float((out[True] - out[False]).abs().max()) < 1e-5 * scale
