@@ -20,7 +20,7 @@ from . import graphprep
 from .jtmpn import JTMPN
 from .jtnn_dec import JTNNDecoder
 from .jtnn_enc import JTNNEncoder
-from .mpn import MPN, as_row_buffer, dense_view
+from .mpn import MPN, as_row_buffer, dense_view, pack_weights
 
 
 class _SegmentCE(torch.autograd.Function):
@@ -93,6 +93,68 @@ class _RowDot(torch.autograd.Function):
         return dense_view(dq, H), dense_view(dc, H), None, None
 
 
+class _LatentHeads(torch.autograd.Function):
+    """x [B, H] -> (W_m x + b_m, -|W_v x + b_v|): the mean and log-variance heads of one encoder
+    (fast_jtnn/jtnn_vae.py:59-64, 69-70).  Forward: two products with the bias in their epilogue; backward: two
+    dgrad products summed into one buffer and two weight-gradient products that carry the bias gradient.  The
+    ``nn.Linear`` calls they replace cost ~0.1 ms of host time each through the BLAS library (twelve calls per
+    encoder and step, forward and backward), which a step of a few hundred molecules cannot hide."""
+
+    @staticmethod
+    def forward(ctx, x, Wm, bm, Wv, bv):
+        dev = x.device
+        B, H = x.shape
+        L = Wm.shape[0]
+        ld, lp = K.round_ld(H), K.round_ld(L)
+        with torch.cuda.device(dev):
+            X = as_row_buffer(x, H, ld)
+            Wm_p, Wv_p = pack_weights([(Wm, 0, H, False), (Wv, 0, H, False)])
+            Y = torch.empty((2, B, lp), dtype=torch.float32, device=dev)
+            for i, (W_p, b) in enumerate(((Wm_p, bm), (Wv_p, bv))):
+                K.gemm_nt(X.data_ptr(), ld, W_p.data_ptr(), ld, Y[i].data_ptr(), lp, B, L, H,
+                          bias=None if b is None else b.detach().data_ptr())
+            pre = Y[1, :, :L]
+            log_var = torch.abs(pre).neg_()
+        if any(ctx.needs_input_grad):
+            ctx.keep = (X, pre, Wm, Wv, H, L, ld, lp, bm is not None, bv is not None)
+        ctx.set_materialize_grads(False)
+        return Y[0, :, :L], log_var
+
+    @staticmethod
+    def backward(ctx, dmean, dlog_var):
+        X, pre, Wm, Wv, H, L, ld, lp, has_bm, has_bv = ctx.keep
+        dev = X.device
+        B = X.shape[0]
+        with torch.cuda.device(dev):
+            dm = None if dmean is None else as_row_buffer(dmean, L, lp)
+            # d(-|p|)/dp = -sign(p) (0 at p = 0, as torch.abs differentiates)
+            dv = None if dlog_var is None else as_row_buffer(torch.sign(pre).neg_().mul_(dlog_var), L, lp)
+            dX = None
+            if ctx.needs_input_grad[0] and (dm is not None or dv is not None):
+                WmT, WvT = pack_weights([(Wm, 0, H, True), (Wv, 0, H, True)])
+                dX = K.rows(B, ld, dev)
+                first = True
+                for d, WT in ((dm, WmT), (dv, WvT)):
+                    if d is None:
+                        continue
+                    K.gemm_nt(d.data_ptr(), lp, WT.data_ptr(), lp, dX.data_ptr(), ld, B, H, L,
+                              add=None if first else dX.data_ptr(), ld_add=ld)
+                    first = False
+                dX = dense_view(dX, H)
+            grads = []
+            for d, W, has_b, need_w, need_b in ((dm, Wm, has_bm, ctx.needs_input_grad[1], ctx.needs_input_grad[2]),
+                                                (dv, Wv, has_bv, ctx.needs_input_grad[3], ctx.needs_input_grad[4])):
+                if d is None or not (need_w or (has_b and need_b)):
+                    grads += [None, None]
+                    continue
+                dW = torch.empty((L, H), dtype=torch.float32, device=dev)
+                db = torch.empty((L,), dtype=torch.float32, device=dev) if has_b else None
+                K.gemm_tn(d.data_ptr(), lp, X.data_ptr(), ld, dW.data_ptr(), H, B, L, H, False, dev,
+                          dbias=None if db is None else db.data_ptr())
+                grads += [dW, db]
+        return (dX, *grads)
+
+
 class JTNNVAE(nn.Module):
     def __init__(self, vocab, hidden_size, latent_size, depthT, depthG, decoder=None):
         """``decoder``: None builds the in-package teacher-forced decoder (as the reference does,
@@ -157,11 +219,17 @@ class JTNNVAE(nn.Module):
 
     def encode_latent(self, jtenc_holder, mpn_holder):  # jtnn_vae.py:56-65
         tree_vecs, _, mol_vecs = self.encode(jtenc_holder, mpn_holder)
-        tree_mean = self.T_mean(tree_vecs)
-        mol_mean = self.G_mean(mol_vecs)
-        tree_var = -torch.abs(self.T_var(tree_vecs))
-        mol_var = -torch.abs(self.G_var(mol_vecs))
+        tree_mean, tree_var = self.latent_heads(tree_vecs, self.T_mean, self.T_var)
+        mol_mean, mol_var = self.latent_heads(mol_vecs, self.G_mean, self.G_var)
         return torch.cat([tree_mean, mol_mean], dim=1), torch.cat([tree_var, mol_var], dim=1)
+
+    @staticmethod
+    def latent_heads(z_vecs, W_mean, W_var):
+        """(W_mean z, -|W_var z|) of fast_jtnn/jtnn_vae.py:59-64 / 69-70 on the package's own products."""
+        if z_vecs.device.type != "cuda":
+            raise RuntimeError("fast_jtnn_hip latent heads run on an MI355X only (input is on %s); there is no CPU "
+                               "path" % z_vecs.device)
+        return _LatentHeads.apply(z_vecs, W_mean.weight, W_mean.bias, W_var.weight, W_var.bias)
 
     def encode_vectors(self, jtenc_holder, mpn_holder):
         """[B, 2H] = cat(tree_vecs, mol_vecs): what bulk latent generation stores
@@ -171,8 +239,7 @@ class JTNNVAE(nn.Module):
 
     def rsample(self, z_vecs, W_mean, W_var, epsilon=None):  # jtnn_vae.py:67-78
         batch_size = z_vecs.size(0)
-        z_mean = W_mean(z_vecs)
-        z_log_var = -torch.abs(W_var(z_vecs))
+        z_mean, z_log_var = self.latent_heads(z_vecs, W_mean, W_var)
         kl_loss = -0.5 * torch.sum(1.0 + z_log_var - z_mean * z_mean - torch.exp(z_log_var)) / batch_size
         if epsilon is None:
             epsilon = torch.randn_like(z_mean)

@@ -387,3 +387,48 @@ def test_default_tile_policy_of_the_two_stream_step_stays_within_rounding():
         out[overlap] = torch.cat([mean, logvar], 1).double()
     scale = float(out[False].abs().max())
     assert float((out[True] - out[False]).abs().max()) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("B,H,L,which", [(64, 450, 28, "both"), (1, 450, 28, "both"), (37, 450, 28, "mean"),
+                                         (37, 450, 28, "var"), (19, 30, 5, "both"), (300, 450, 28, "frozen_input")])
+def test_latent_heads_match_linear_layers_in_fp64(B, H, L, which):
+    """JTNNVAE.latent_heads (mean = W_m x + b_m, log-variance = -|W_v x + b_v|, fast_jtnn/jtnn_vae.py:59-64) on
+    the package's products against nn.Linear in fp64: outputs, input gradient, weight and bias gradients; with
+    only one of the two outputs used, a latent size that is no multiple of four, and an input without gradient."""
+    from fast_jtnn_hip import JTNNVAE
+    gen = torch.Generator(device="cpu").manual_seed(B * 1000 + L)
+    Wm, Wv = torch.nn.Linear(H, L), torch.nn.Linear(H, L)
+    with torch.no_grad():
+        for p in list(Wm.parameters()) + list(Wv.parameters()):
+            p.copy_(0.3 * torch.randn(p.shape, generator=gen))
+    x = torch.randn((B, H), generator=gen)
+    gm, gv = torch.randn((B, L), generator=gen), torch.randn((B, L), generator=gen)
+
+    def run(dev, dtype):
+        m, v = (torch.nn.Linear(H, L).to(device=dev, dtype=dtype) for _ in range(2))
+        m.load_state_dict(Wm.state_dict())
+        v.load_state_dict(Wv.state_dict())
+        xx = x.to(device=dev, dtype=dtype).requires_grad_(which != "frozen_input")
+        if dev == "cuda":
+            mean, lv = JTNNVAE.latent_heads(xx, m, v)
+        else:
+            mean, lv = m(xx), -torch.abs(v(xx))
+        loss = 0.0
+        if which != "var":
+            loss = loss + (mean * gm.to(device=dev, dtype=dtype)).sum()
+        if which != "mean":
+            loss = loss + (lv * gv.to(device=dev, dtype=dtype)).sum()
+        loss.backward()
+        out = {"mean": mean, "lv": lv, "dx": xx.grad}
+        for tag, mod in (("m", m), ("v", v)):
+            out["dW" + tag], out["db" + tag] = mod.weight.grad, mod.bias.grad
+        return {k: (None if t is None else t.detach().double().cpu()) for k, t in out.items()}
+
+    got, want = run("cuda", torch.float32), run("cpu", torch.float64)
+    for k in want:
+        if want[k] is None:
+            assert got[k] is None or float(got[k].abs().max()) == 0.0, k
+            continue
+        assert got[k] is not None, k
+        scale = float(want[k].abs().max()) + 1e-30
+        assert float((got[k] - want[k]).abs().max()) < 2e-5 * scale, k
