@@ -480,6 +480,157 @@ __global__ __launch_bounds__(256, NACC > 3 ? 2 : 3) void nt_v2(const float* __re
   }
 }
 
+
+// v5: one block owns 128 rows x ALL columns (15 column tiles), eight waves = four row groups x two column halves
+// (tiles 0-7 and 8-14), two waves per SIMD.  Each A element is loaded by two waves (not five blocks), straight into
+// registers in the matrix instruction's own layout (lane (r, h): row r, k = 8h .. 8h + 8 of a K step of 16) and split
+// there; W arrives pre-split and streams through a two-stage LDS ring of [3 planes][480 rows][16 k] bf16 (46 KB a
+// stage), whose 32-byte rows make every fragment read and every staging write one contiguous kilobyte per wave.
+// One barrier per K step of 16; per step a wave issues 48 (42) matrix instructions against ~25 vector and 9 LDS ones.
+constexpr int V5_ROWS = 480, V5_PLANE = V5_ROWS * 32, V5_STAGE = 3 * V5_PLANE;
+
+// the matrix work of one K step for a wave with NT column tiles: the three W fragments of tile t + 1 are requested
+// before the six instructions of tile t are issued (sched_group_barrier pins that order), so the LDS latency of a
+// tile hides behind the 192 cycles of the tile before it
+template <int NT>
+__device__ __forceinline__ void v5_step(f32x16 (&acc)[8], const bf16x8 a1, const bf16x8 a2, const bf16x8 a3,
+                                        const unsigned char* wb) {
+  bf16x8 b[2][3];
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) b[0][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * V5_PLANE);
+#ifndef V5_NO_SCHED
+  __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // the first tile's fragments
+#endif
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = t & 1;
+    if (t + 1 < NT) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        b[c ^ 1][pl] = *reinterpret_cast<const bf16x8*>(wb + pl * V5_PLANE + (t + 1) * 1024);
+    }
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b[c][0], acc[t], 0, 0, 0);
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[c][2], acc[t], 0, 0, 0);
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[c][1], acc[t], 0, 0, 0);
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b[c][0], acc[t], 0, 0, 0);
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[c][1], acc[t], 0, 0, 0);
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b[c][0], acc[t], 0, 0, 0);
+#ifndef V5_NO_SCHED
+    if (t + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // 3 LDS reads (next tile)
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                  // 6 matrix instructions (this tile)
+#endif
+  }
+}
+
+template <int CHALF>
+__device__ __forceinline__ void v5_body(const float* __restrict__ A, int lda, float* __restrict__ C, int ldc, int M,
+                                        int N, int K, const u32x4* __restrict__ Wp, int wp_rows, int wp_ld8,
+                                        unsigned char* smem) {
+  constexpr int T0 = CHALF ? 8 : 0, NT = CHALF ? 7 : 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rg = wave & 3;
+  const int m0 = blockIdx.x * BM;
+  const int r = lane & 31, h = lane >> 5;
+  constexpr int WCH = 3 * V5_ROWS * 2;  // 16-byte chunks of a stage
+  constexpr int WPT = (WCH + 511) / 512;
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  const float* a_row = A + (size_t)min(m0 + rg * 32 + r, M - 1) * lda + 8 * h;
+  float4 ra[2];
+  u32x4 rw[WPT];
+  const int nk = (K + 15) / 16;
+  auto load_a = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = 16 * s + 8 * h + 4 * i;
+      ra[i] = *reinterpret_cast<const float4*>(a_row + (k + 3 < lda ? 16 * s + 4 * i : -8 * h));
+    }
+  };
+  auto load_w = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = min(tid + 512 * i, WCH - 1);
+      const int plane = c / (V5_ROWS * 2), rc = c % (V5_ROWS * 2), row = rc >> 1, ch = rc & 1;
+      rw[i] = Wp[((size_t)plane * wp_rows + row) * wp_ld8 + 2 * s + ch];
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int c = min(tid + 512 * i, WCH - 1);
+      *reinterpret_cast<u32x4*>(smem + buf * V5_STAGE + 16 * c) = rw[i];  // chunk c = (plane, row, half) in order
+    }
+  };
+  load_a(0);
+  load_w(0);
+  store_w(0);
+  __syncthreads();
+  for (int s = 0; s < nk; ++s) {
+    const bool more = s + 1 < nk;
+    float4 v[2] = {ra[0], ra[1]};
+    if (s == nk - 1 && (K & 15)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int k = 16 * s + 8 * h + 4 * i;
+        v[i].x = k + 0 < K ? v[i].x : 0.f;
+        v[i].y = k + 1 < K ? v[i].y : 0.f;
+        v[i].z = k + 2 < K ? v[i].z : 0.f;
+        v[i].w = k + 3 < K ? v[i].w : 0.f;
+      }
+    }
+    if (more) {
+      load_a(s + 1);
+      load_w(s + 1);
+    }
+    unsigned p[3][4];
+    split3(v[0].x, v[0].y, p[0][0], p[1][0], p[2][0]);
+    split3(v[0].z, v[0].w, p[0][1], p[1][1], p[2][1]);
+    split3(v[1].x, v[1].y, p[0][2], p[1][2], p[2][2]);
+    split3(v[1].z, v[1].w, p[0][3], p[1][3], p[2][3]);
+    const u32x4 q1 = {p[0][0], p[0][1], p[0][2], p[0][3]};
+    const u32x4 q2 = {p[1][0], p[1][1], p[1][2], p[1][3]};
+    const u32x4 q3 = {p[2][0], p[2][1], p[2][2], p[2][3]};
+    const bf16x8 a1 = __builtin_bit_cast(bf16x8, q1), a2 = __builtin_bit_cast(bf16x8, q2),
+                 a3 = __builtin_bit_cast(bf16x8, q3);
+#ifdef V5_NO_LDSREAD
+    const unsigned char* wb = smem + (s & 1) * V5_STAGE + 16 * h - (size_t)lane * 0;
+    v5_step<NT>(acc, a1, a2, a3, smem + 16 * lane - 1024 * 0);
+#else
+    const unsigned char* wb = smem + (s & 1) * V5_STAGE + (32 * T0 + r) * 32 + 16 * h;
+    v5_step<NT>(acc, a1, a2, a3, wb);
+#endif
+    if (more) store_w((s + 1) & 1);
+#ifndef V5_NO_BARRIER
+    __syncthreads();
+#endif
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = m0 + rg * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+    if (i >= M) continue;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int n = 32 * (T0 + t) + r;
+      if (n < N) C[(size_t)i * ldc + n] = acc[t][q];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void nt_v5(const float* __restrict__ A, int lda, float* __restrict__ C, int ldc,
+                                                int M, int N, int K, const u32x4* __restrict__ Wp, int wp_rows,
+                                                int wp_ld8) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * V5_STAGE];
+  if (threadIdx.x >> 8)
+    v5_body<1>(A, lda, C, ldc, M, N, K, Wp, wp_rows, wp_ld8, smem);
+  else
+    v5_body<0>(A, lda, C, ldc, M, N, K, Wp, wp_rows, wp_ld8, smem);
+}
+
 // v3: K steps of 16 through a two-stage LDS ring.  While the matrix instructions of step s run from stage s & 1, the
 // same wave splits the (already arrived) global values of step s + 1 and writes them into the other stage, in program
 // order between the groups of matrix instructions, and the loads of step s + 2 are in flight: one barrier per step,
@@ -799,9 +950,11 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const bool use_v2 = getenv("V2") != nullptr, use_v3 = getenv("V3") != nullptr;
-  const bool use_v4 = getenv("V4") != nullptr;
+  const bool use_v4 = getenv("V4") != nullptr, use_v5 = getenv("V5") != nullptr;
   auto launch = [&]() {
-    if (use_v4)
+    if (use_v5)
+      hipLaunchKernelGGL(nt_v5, dim3(ntm), dim3(512), 0, 0, dA, ld, dC, ld, M, N, K, (const u32x4*)dWp, wp_rows, wp_ld8);
+    else if (use_v4)
       hipLaunchKernelGGL(nt_v4<NACC>, dim3(ntm * ntn), dim3(256), 0, 0, dA, ld, dC, ld, M, N, K, ntn,
                          (const u32x4*)dWp, wp_rows, wp_ld8);
     else if (use_v3)
