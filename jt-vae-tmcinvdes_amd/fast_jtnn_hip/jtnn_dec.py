@@ -34,6 +34,7 @@ import torch.nn.functional as F
 
 from . import graphprep
 from .jtnn_enc import _MessageGRUFunction
+from .linear import linear, table_linear
 from .nnutils import csr_gather_sum
 
 MAX_NB = 15  # fast_jtnn/jtnn_dec.py:9
@@ -181,15 +182,20 @@ class JTNNDecoder(nn.Module):
         self.W_o = nn.Linear(hidden_size, self.vocab_size)
         self.U_o = nn.Linear(hidden_size, 1)
 
-    def aggregate(self, hiddens, contexts, x_tree_vecs, mode):  # jtnn_dec.py:42-53
+    def aggregate(self, hiddens, contexts, x_tree_vecs, mode, contexts32=None):  # jtnn_dec.py:42-53
+        """``contexts32``: ``contexts`` as int32 on the device, if the caller keeps it."""
         if mode == "word":
             V, V_o = self.W, self.W_o
         elif mode == "stop":
             V, V_o = self.U, self.U_o
         else:
             raise ValueError("aggregate mode is wrong")
-        tree_contexts = x_tree_vecs.index_select(0, contexts)
-        return V_o(F.relu(V(torch.cat([hiddens, tree_contexts], dim=-1))))
+        if contexts32 is None:
+            contexts32 = contexts.to(device=hiddens.device, dtype=torch.int32)
+        # V(cat([hiddens, x_tree_vecs[contexts]])) without the concatenation: the tree vectors go through their 28
+        # columns of V once per tree and are added per row in the epilogue of the product over `hiddens`
+        hid = table_linear(hiddens, x_tree_vecs, contexts32, V, h_first=True, relu=True)
+        return linear(hid, V_o) if mode == "word" else V_o(hid)  # U_o has one output column: a matrix-vector product
 
     def messages(self, prep):
         """Hidden rows of all directed edges of the batch's traces, [n_mess, H] (row 0 = padding)."""
@@ -230,9 +236,10 @@ class JTNNDecoder(nn.Module):
                     prep = graphprep.prepare_message_dag(plan.mess_word, plan.dep_rp, plan.dep_col, self.vocab_size,
                                                          dev)
                 cache[str(dev)] = ([t.long() for t in idx32], stop_csr, stop_csr_t,
-                                   torch.from_numpy(np.ascontiguousarray(plan.stop_target)).to(dev), prep)
-            (pred_mess, pred_ctx, pred_target, stop_word, stop_ctx), stop_csr, stop_csr_t, stop_target, prep = \
-                cache[str(dev)]
+                                   torch.from_numpy(np.ascontiguousarray(plan.stop_target)).to(dev), prep,
+                                   (idx32[1], idx32[3], idx32[4]))
+            (pred_mess, pred_ctx, pred_target, stop_word, stop_ctx), stop_csr, stop_csr_t, stop_target, prep, \
+                (pred_ctx32, stop_word32, stop_ctx32) = cache[str(dev)]
             if prep is not None:
                 mess = self.messages(prep)
             else:  # single-node trees only: nothing is ever passed
@@ -240,14 +247,15 @@ class JTNNDecoder(nn.Module):
 
             # word prediction: the root from a zero row, every child from the message that reaches it
             pred_hiddens = torch.cat([x_tree_vecs.new_zeros((B, H)), mess.index_select(0, pred_mess)], dim=0)
-            pred_scores = self.aggregate(pred_hiddens, pred_ctx, x_tree_vecs, "word")
+            pred_scores = self.aggregate(pred_hiddens, pred_ctx, x_tree_vecs, "word", pred_ctx32)
             pred_loss = F.cross_entropy(pred_scores, pred_target, reduction="sum") / B
             pred_acc = (pred_scores.argmax(dim=1) == pred_target).float().sum() / pred_target.nelement()
 
             # stop prediction: clique embedding and the sum of everything that has reached the node
             cur_o = csr_gather_sum(mess, stop_csr, stop_csr_t)
-            stop_hiddens = F.relu(self.U_i(torch.cat([self.embedding(stop_word), cur_o], dim=1)))
-            stop_scores = self.aggregate(stop_hiddens, stop_ctx, x_tree_vecs, "stop").squeeze(-1)
+            # U_i(cat([embedding[stop_word], cur_o])): the embedding half as a per-word table       (jtnn_dec.py:160-163)
+            stop_hiddens = table_linear(cur_o, self.embedding.weight, stop_word32, self.U_i, h_first=False, relu=True)
+            stop_scores = self.aggregate(stop_hiddens, stop_ctx, x_tree_vecs, "stop", stop_ctx32).squeeze(-1)
             stop_loss = F.binary_cross_entropy_with_logits(stop_scores, stop_target, reduction="sum") / B
             stop_acc = ((stop_scores >= 0).float() == stop_target).float().sum() / stop_target.nelement()
             if not sync:

@@ -432,3 +432,74 @@ def test_latent_heads_match_linear_layers_in_fp64(B, H, L, which):
         assert got[k] is not None, k
         scale = float(want[k].abs().max()) + 1e-30
         assert float((got[k] - want[k]).abs().max()) < 2e-5 * scale, k
+
+
+@pytest.mark.parametrize("n,nh,m,ns,out_f,h_first,relu", [(700, 450, 33, 28, 450, True, True),
+                                                          (12001, 450, 385, 450, 450, False, True),
+                                                          (5, 450, 3, 28, 450, True, False),
+                                                          (257, 30, 9, 6, 22, False, True)])
+def test_table_linear_matches_the_concatenated_linear_layer_in_fp64(n, nh, m, ns, out_f, h_first, relu):
+    """linear.table_linear = act(lin(cat([h, src[idx]]))) (or the other order) as the decoder's heads use it
+    (fast_jtnn/jtnn_dec.py:42-53, 160-163): output and the gradients of h, src, weight and bias against the
+    concatenation run in fp64; rows of src that no index names get a zero gradient."""
+    from fast_jtnn_hip.linear import table_linear
+    gen = torch.Generator(device="cpu").manual_seed(n + 7 * m)
+    lin = torch.nn.Linear(nh + ns, out_f)
+    with torch.no_grad():
+        lin.weight.copy_(0.2 * torch.randn(lin.weight.shape, generator=gen))
+        lin.bias.copy_(0.2 * torch.randn(lin.bias.shape, generator=gen))
+    h, src = torch.randn((n, nh), generator=gen), torch.randn((m, ns), generator=gen)
+    idx = torch.randint(0, max(m - 1, 1), (n,), generator=gen)  # the last row of src is never read
+    g = torch.randn((n, out_f), generator=gen)
+
+    def run(dev, dtype, on=None):
+        mod = torch.nn.Linear(nh + ns, out_f).to(device=dev, dtype=dtype)
+        mod.load_state_dict(lin.state_dict())
+        hh = h.to(device=dev, dtype=dtype).requires_grad_(True)
+        ss = src.to(device=dev, dtype=dtype).requires_grad_(True)
+        if dev == "cuda":
+            y = table_linear(hh, ss, idx.to(device=dev, dtype=torch.int32), mod, h_first=h_first, relu=relu)
+        else:
+            parts = [hh, ss[idx]] if h_first else [ss[idx], hh]
+            y = mod(torch.cat(parts, 1))
+            if relu:
+                # a unit whose pre-activation is within rounding of zero may switch differently in fp32: the
+                # reference takes the switches of the run it is compared with (and checks that only such units differ)
+                differ = y.detach()[(y.detach() > 0) != on]
+                assert differ.numel() == 0 or float(differ.abs().max()) < 1e-4
+                y = y * on
+        (y * g.to(device=dev, dtype=dtype)).sum().backward()
+        out = {"y": y, "dh": hh.grad, "dsrc": ss.grad, "dW": mod.weight.grad, "db": mod.bias.grad}
+        return {k: t.detach().double().cpu() for k, t in out.items()}
+
+    got = run("cuda", torch.float32)
+    want = run("cpu", torch.float64, got["y"] > 0)
+    for k in want:
+        scale = float(want[k].abs().max()) + 1e-30
+        assert float((got[k] - want[k]).abs().max()) < 3e-5 * scale, k
+    assert float(got["dsrc"][m - 1].abs().max()) == 0.0 or m == 1
+
+
+@pytest.mark.parametrize("n,kin,out_f", [(900, 450, 385), (20000, 450, 385), (3, 450, 1), (64, 30, 7)])
+def test_linear_matches_nn_linear_in_fp64(n, kin, out_f):
+    from fast_jtnn_hip.linear import linear
+    gen = torch.Generator(device="cpu").manual_seed(n + kin)
+    lin = torch.nn.Linear(kin, out_f)
+    with torch.no_grad():
+        lin.weight.copy_(0.2 * torch.randn(lin.weight.shape, generator=gen))
+        lin.bias.copy_(0.2 * torch.randn(lin.bias.shape, generator=gen))
+    x, g = torch.randn((n, kin), generator=gen), torch.randn((n, out_f), generator=gen)
+
+    def run(dev, dtype):
+        mod = torch.nn.Linear(kin, out_f).to(device=dev, dtype=dtype)
+        mod.load_state_dict(lin.state_dict())
+        xx = x.to(device=dev, dtype=dtype).requires_grad_(True)
+        y = linear(xx, mod) if dev == "cuda" else mod(xx)
+        (y * g.to(device=dev, dtype=dtype)).sum().backward()
+        out = {"y": y, "dx": xx.grad, "dW": mod.weight.grad, "db": mod.bias.grad}
+        return {k: t.detach().double().cpu() for k, t in out.items()}
+
+    got, want = run("cuda", torch.float32), run("cpu", torch.float64)
+    for k in want:
+        scale = float(want[k].abs().max()) + 1e-30
+        assert float((got[k] - want[k]).abs().max()) < 3e-5 * scale, k
