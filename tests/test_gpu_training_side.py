@@ -122,6 +122,7 @@ def test_two_stream_step_is_bitwise_the_one_stream_step(B, atoms, crowded):
     g, x_batch = _seeded_training_problem(77, B, atoms)
     hip = make_hip_model(g, "cuda")
     hip.jtnn.crowded = crowded
+    hip.overlap_min_messages = 0  # two streams whatever the batch size
     _, jt, mp, _ = x_batch()
 
     def step(overlap):
@@ -376,6 +377,7 @@ def test_default_tile_policy_of_the_two_stream_step_stays_within_rounding():
     largest entry (fp32 sums of 450 terms, five levels deep)."""
     g, x_batch = _seeded_training_problem(78, 64, 30.0)
     hip = make_hip_model(g, "cuda")
+    hip.overlap_min_messages = 0
     assert hip.jtnn.crowded is None
     _, jt, mp, _ = x_batch()
     out = {}
