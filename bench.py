@@ -280,15 +280,26 @@ def fresh_holder_rate(model, args, device, rank, step_on):
     def unseen(b):  # new tensor objects: nothing prepared is attached to them
         return tuple(tuple(x.clone() if isinstance(x, torch.Tensor) else x for x in h) for h in b)
 
+    issued = [0.0, 0.0]
+
     def run(source):
         it = iter(source)
         step_on(*next(it))  # allocator warm-up on these shapes
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         n = 0
-        for jt, mp in it:
+        waited = 0.0
+        while True:
+            w0 = time.perf_counter()
+            try:
+                jt, mp = next(it)
+            except StopIteration:
+                break
+            waited += time.perf_counter() - w0
             step_on(jt, mp)
             n += 1
+        issued[0] = (time.perf_counter() - t0) / n  # the loop alone: drawing batches and issuing their steps
+        issued[1] = waited / n                      # of which: waiting for the next batch
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n
 
@@ -321,6 +332,7 @@ def fresh_holder_rate(model, args, device, rank, step_on):
     workers = default_workers()
     pf = Prefetcher(ids * 2, build, device, workers=workers)
     dt_flat_pf = run(pf)
+    issue_flat_pf, wait_flat_pf = issued
     pf.close()
     return {"value_fresh_holders": round(args.batch / dt, 1), "ms_per_step_fresh_holders": round(1e3 * dt, 3),
             "value_fresh_holders_prefetched": round(args.batch / dt_pf, 1),
@@ -328,6 +340,8 @@ def fresh_holder_rate(model, args, device, rank, step_on):
             "value_from_flat_storage": round(args.batch / dt_flat, 1),
             "value_from_flat_storage_prefetched": round(args.batch / dt_flat_pf, 1),
             "ms_per_step_from_flat_storage_prefetched": round(1e3 * dt_flat_pf, 3),
+            "host_loop_ms_per_step_from_flat_storage_prefetched": round(1e3 * issue_flat_pf, 3),
+            "host_wait_for_batch_ms_per_step_from_flat_storage_prefetched": round(1e3 * wait_flat_pf, 3),
             "tensorize_and_prepare_host_ms_per_batch": round(host_ms, 3),
             "host_threads": {"native_builder_threads": threads, "prefetch_workers": workers,
                              "cpu_count": os.cpu_count()},

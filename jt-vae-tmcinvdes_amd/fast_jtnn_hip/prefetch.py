@@ -161,5 +161,8 @@ def default_workers() -> int:
     that many (a worker also spends part of its time inside multi-threaded native builders), fewer otherwise."""
     import os
 
+    env = os.environ.get("JTVAE_PREFETCH_WORKERS")
+    if env:
+        return max(1, int(env))
     world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
     return max(1, min(3, (os.cpu_count() or 1) // (2 * world)))
