@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 17
+#define JTVAE_ABI_VERSION 18
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -418,6 +418,47 @@ typedef struct jtvae_tree_bwd {
   const int64_t* off_j;
 } jtvae_tree_bwd_t;
 int jtvae_tree_gru_backward(const jtvae_tree_bwd_t* args, void* stream);
+
+/* Everything of JTNNEncoder's backward pass that surrounds the level sweep (autograd of fast_jtnn/jtnn_enc.py:27-41
+ * and of the per-word table products that replace its W_z / W_r / W_h / outputNN input halves), as ONE host call:
+ * the root stage (ReLU mask, W_out gradient, gradient into the messages that reach a root), the sweep
+ * (jtvae_tree_gru_backward on `sweep`), the three weight-gradient contractions of the recurrence, the four table
+ * gradients (two keyed sums and one contraction each) and the embedding gradient.  `side` (or NULL) is a second
+ * stream for the groups of launches nothing on the main chain waits for (root-stage weight gradients beside the
+ * sweep, recurrence weight gradients beside the table gradients); the call forks and joins it with events of its
+ * own, so on return everything is ordered on `stream`.  The same launches in the same order on the same data as
+ * issuing them one by one: bit-identical.  A keyed sum is two gathers: `*_pieces` sums runs of source rows, `*_key`
+ * sums the pieces of a table row.  crowded != 0: products of <= 512 rows take the 128 x 32 tiling for the duration
+ * of the call (jtvae_set_small_tile_rows(0)).  ws[i] / ws_bytes[i]: one jtvae_gemm_tn workspace per contraction
+ * (0: W_out h-half, 1: o table, 2: z h-half, 3: h h-half, 4: U_r, 5: z table, 6: h table, 7: r table). */
+typedef struct jtvae_csr {
+  const int32_t* rowptr;
+  const int32_t* col;
+  int32_t n_rows;
+} jtvae_csr_t;
+typedef struct jtvae_tree_enc_bwd {
+  int32_t NM, B, NW, V, H, ld, crowded;
+  const float *Eu, *nsum, *tv;          /* kept by the forward pass: word rows used, root sums, root outputs */
+  const float* dtv;                     /* [B, ld] gradient of tree_vecs, or NULL (zero) */
+  const float* dmess;                   /* gradient of messages (rows ld_dmess apart), or NULL */
+  int32_t ld_dmess;
+  const float *WohT, *WzxT, *WhxT, *WoxT, *WrT; /* transposed weight blocks [H, ld] */
+  jtvae_csr_t ident, root_t, word_t;    /* identity over B; root sums transposed (NM rows); word rows -> vocabulary (V rows) */
+  jtvae_csr_t o_pieces, o_key, zh_pieces, zh_key, r_pieces, r_key; /* keyed sums into the NW table rows */
+  const jtvae_tree_bwd_t* sweep;        /* its dh / dz / dp / du / a_r are read and written here too */
+  int32_t n_e;                          /* rows of sweep->dz and sweep->dp */
+  const float *ss, *gs, *hs;            /* saved s, g, h by message id */
+  const int32_t *zx, *zy, *ux, *uy;     /* row pairs of the recurrence's weight gradients */
+  int32_t n_z, n_u;
+  float *dpre_root, *dnsum, *part_side, *part_main, *dPo, *dPz, *dPh, *dPr, *dEu, *dE_p; /* scratch row buffers */
+  void* ws[8];
+  size_t ws_bytes[8];
+  float *dWout, *dWz, *dWh;             /* [H, 2H] dense */
+  float *dWr, *dUr;                     /* [H, H] dense */
+  float *dbout, *dbz, *dbh, *dbu;       /* [H] */
+  float* dE;                            /* [V, H] dense */
+} jtvae_tree_enc_bwd_t;
+int jtvae_tree_encoder_backward(const jtvae_tree_enc_bwd_t* args, void* stream, void* side);
 
 /* out[i] = slab sel[i] of base, row i: collects the final value of every message
  * (sel[i] = min(depth, sf[i])). */

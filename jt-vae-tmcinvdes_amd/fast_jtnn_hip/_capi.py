@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("JTVAE_HIP_LIB") or os.path.join(_HERE, "libjtvae_hip.
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class Epilogue(C.Structure):
@@ -82,6 +82,25 @@ class TreeBwd(C.Structure):
                 [(n, C.c_int32) for n in ("T", "H", "ld", "pad_row", "n_levels")] +
                 [("e_rows", C.POINTER(C.c_void_p)), ("e_n", C.POINTER(C.c_int32)), ("n_dep", C.POINTER(C.c_int32)),
                  ("off_e", C.POINTER(C.c_int64)), ("off_j", C.POINTER(C.c_int64))])
+
+
+class Csr(C.Structure):  # jtvae_csr_t
+    _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("n_rows", C.c_int32)]
+
+
+class TreeEncBwd(C.Structure):  # jtvae_tree_enc_bwd_t
+    _fields_ = ([(n, C.c_int32) for n in ("NM", "B", "NW", "V", "H", "ld", "crowded")] +
+                [(n, C.c_void_p) for n in ("Eu", "nsum", "tv", "dtv", "dmess")] + [("ld_dmess", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("WohT", "WzxT", "WhxT", "WoxT", "WrT")] +
+                [(n, Csr) for n in ("ident", "root_t", "word_t", "o_pieces", "o_key", "zh_pieces", "zh_key",
+                                    "r_pieces", "r_key")] +
+                [("sweep", C.POINTER(TreeBwd)), ("n_e", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("ss", "gs", "hs", "zx", "zy", "ux", "uy")] +
+                [("n_z", C.c_int32), ("n_u", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("dpre_root", "dnsum", "part_side", "part_main", "dPo", "dPz", "dPh", "dPr",
+                                           "dEu", "dE_p")] +
+                [("ws", C.c_void_p * 8), ("ws_bytes", C.c_size_t * 8)] +
+                [(n, C.c_void_p) for n in ("dWout", "dWz", "dWh", "dWr", "dUr", "dbout", "dbz", "dbh", "dbu", "dE")])
 
 
 class PackItem(C.Structure):
@@ -178,6 +197,7 @@ SIGNATURES = {
     "jtvae_set_small_tile_rows": (C.c_int, [C.c_int]),
     "jtvae_tree_gru_forward": (C.c_int, [_vp, _vp]),
     "jtvae_tree_gru_backward": (C.c_int, [_vp, _vp]),
+    "jtvae_tree_encoder_backward": (C.c_int, [_vp, _vp, _vp]),
     "jtvae_graph_mpn_forward": (C.c_int, [_vp, _vp]),
     "jtvae_graph_mpn_backward": (C.c_int, [_vp, _vp]),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
@@ -535,6 +555,16 @@ def tree_gru_forward(args):
 
 def tree_gru_backward(args):
     check(lib.jtvae_tree_gru_backward(C.byref(args), stream_ptr()), "tree_gru_backward")
+
+
+def tree_encoder_backward(args, side=None):
+    """``side``: raw handle of the helper stream, or None."""
+    check(lib.jtvae_tree_encoder_backward(C.byref(args), stream_ptr(), side), "tree_encoder_backward")
+
+
+def csr_arg(csr, n_rows=None):
+    """jtvae_csr_t of an uploaded CSR (``rowptr`` / ``col`` device tensors)."""
+    return Csr(csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.n_rows if n_rows is None else n_rows)
 
 
 def pointer_array(tensors):

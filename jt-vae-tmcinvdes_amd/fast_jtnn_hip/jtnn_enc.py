@@ -118,9 +118,11 @@ class _TreeGRU:
         return h, st
 
     @staticmethod
-    def backward(dh, sched, bs, NM, H, ld, dev, st, Pr, wid, mcsr_t, WzhT, WhhT, UrT, pad_row=0):
+    def backward(dh, sched, bs, NM, H, ld, dev, st, Pr, wid, mcsr_t, WzhT, WhhT, UrT, pad_row=0, issue=None):
         """dh: gradient w.r.t. the final h (row buffer indexed by message, modified in place).
-        Returns compact (dz [nE], dp [nE], du [nJ]) and A_r [NM] for the weight / table gradients."""
+        Returns compact (dz [nE], dp [nE], du [nJ]) and A_r [NM] for the weight / table gradients.
+        ``issue(args, buffers)``: called with the sweep's argument block instead of issuing the sweep (one-call
+        schedule only)."""
         T = sched.T
         hs, zs, ps, ss, gs, ts, us = (st[k] for k in ("hs", "zs", "ps", "ss", "gs", "ts", "us"))
         stride = st["stride"]
@@ -146,6 +148,9 @@ class _TreeGRU:
                           dp=dp.data_ptr(), du=du.data_ptr(), ds=ds.data_ptr(), dg=dg.data_ptr(),
                           dhdir=dhdir.data_ptr(), a_r=a_r.data_ptr(), T=T, H=H, ld=ld, pad_row=pad_row,
                           n_levels=len(bs.E), e_rows=e_rows, e_n=e_n, n_dep=n_dep, off_e=off_e, off_j=off_j)
+            if issue is not None:  # the caller issues the sweep inside a larger host call
+                issue(a, (dz, dp, du, a_r, ds, dg, dhdir))
+                return dz, dp, du, a_r
             K.tree_gru_backward(a)
             return dz, dp, du, a_r
         if bs.once:
@@ -336,6 +341,10 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         WohT, WzhT, WhhT, UrT, WzxT, WhxT, WoxT, WrT = pack_weights(
             [(Wout, H, H, True), (Wz, H, H, True), (Wh, H, H, True), (Ur_w, 0, H, True), (Wz, 0, H, True),
              (Wh, 0, H, True), (Wout, 0, H, True), (Wr, 0, H, True)])
+        if K.sweeps_enabled() and T >= 1 and bs.once and bs.nE > 0 and bs.n_z > 0 and bs.n_u > 0:
+            return _JTNNEncoderFunction._backward_one_call(
+                ctx, dtv, dmess, bs, (dWout, dWz, dWh, dWr, dUr, dbout, dbz, dbu, dbh),
+                (WohT, WzhT, WhhT, UrT, WzxT, WhxT, WoxT, WrT))
         # root stage: relu mask, W_out[:, H:] gradient, back to the messages that feed a root
         dpre_root = K.rows(B, ld, dev)
         if dtv is None:
@@ -424,6 +433,70 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         # the recurrence's weight gradients are not read here: their stream is joined last, so the embedding chain
         # above runs beside them
         _join(ev_w, dev)
+        return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None, None, None, None
+
+
+    @staticmethod
+    def _backward_one_call(ctx, dtv, dmess, bs, grads, packed):
+        """The backward pass as ONE host call (jtvae_tree_encoder_backward): the launches of ``backward`` in the same
+        order on the same data, the helper stream forked and joined inside the call."""
+        P, depth, H, ld = ctx.prep, ctx.depth, ctx.H, ctx.ld
+        Eu, Pr, nsum, tv, _, _, _, _, _ = ctx.keep
+        st, sched = ctx.st, ctx.sched
+        dev = Eu.device
+        NM, B, NW, V = P.n_mess, P.n_trees, P.n_words, ctx.vocab
+        dWout, dWz, dWh, dWr, dUr, dbout, dbz, dbu, dbh = grads
+        WohT, WzhT, WhhT, UrT, WzxT, WhxT, WoxT, WrT = packed
+        dh = K.rows(NM, ld, dev)
+        if dmess is not None and not (dmess.stride(1) == 1 and dmess.stride(0) >= H):
+            dmess = dmess.contiguous()  # e.g. a broadcast gradient (stride 0)
+        n_side = P.key_r_pieces.n_rows
+        n_main = max(bs.key_pieces.n_rows, P.key_m_pieces.n_rows)
+        # every scratch row buffer of the pass in one allocation
+        sizes = (B, B, n_side, n_main, NW, NW, NW, NW, NW, V)
+        arena = K.rows(sum(max(n, 1) for n in sizes), ld, dev)
+        ptrs, row = [], 0
+        for n in sizes:
+            ptrs.append(arena.data_ptr() + row * ld * 4)
+            row += max(n, 1)
+        dpre_root, dnsum, part_side, part_main, dPo, dPz, dPh, dPr, dEu, dE_p = ptrs
+        shapes = ((B, H, H), (NW, H, H), (bs.n_z, H, H), (bs.n_z, H, H), (bs.n_u, H, H), (NW, H, H), (NW, H, H),
+                  (NW, H, H))
+        ws_bytes = [max(K.gemm_tn_workspace_bytes(*sh), 16) for sh in shapes]
+        offs, tot = [], 0
+        for nb in ws_bytes:
+            offs.append(tot)
+            tot += (nb + 255) // 256 * 256
+        ws = torch.empty((tot,), dtype=torch.uint8, device=dev)
+        dE = torch.empty((V, H), dtype=torch.float32, device=dev)
+        dtv_p = None if dtv is None else as_row_buffer(dtv, H, ld)
+        side = ctx.side_streams[0].cuda_stream if len(ctx.side_streams) > 0 else None
+        NWk = lambda c: K.csr_arg(c, NW)  # noqa: E731
+        out = {}
+
+        def issue(sweep, buffers):
+            a = K.TreeEncBwd(
+                NM=NM, B=B, NW=NW, V=V, H=H, ld=ld, crowded=1 if ctx.crowded else 0, Eu=Eu.data_ptr(),
+                nsum=nsum.data_ptr(), tv=tv.data_ptr(), dtv=None if dtv_p is None else dtv_p.data_ptr(),
+                dmess=None if dmess is None else dmess.data_ptr(), ld_dmess=0 if dmess is None else dmess.stride(0),
+                WohT=WohT.data_ptr(), WzxT=WzxT.data_ptr(), WhxT=WhxT.data_ptr(), WoxT=WoxT.data_ptr(),
+                WrT=WrT.data_ptr(), ident=K.csr_arg(P.ident, B), root_t=K.csr_arg(P.rcsr_t, NM),
+                word_t=K.csr_arg(P.word_csr_t, V), o_pieces=K.csr_arg(P.key_r_pieces), o_key=NWk(P.key_r),
+                zh_pieces=K.csr_arg(bs.key_pieces), zh_key=NWk(bs.key), r_pieces=K.csr_arg(P.key_m_pieces),
+                r_key=NWk(P.key_m), sweep=K.C.pointer(sweep), n_e=max(bs.nE, 1), ss=st["ss"].data_ptr(),
+                gs=st["gs"].data_ptr(), hs=st["hs"].data_ptr(), zx=bs.zx.data_ptr(), zy=bs.zy.data_ptr(),
+                ux=bs.ux.data_ptr(), uy=bs.uy.data_ptr(), n_z=bs.n_z, n_u=bs.n_u, dpre_root=dpre_root, dnsum=dnsum,
+                part_side=part_side, part_main=part_main, dPo=dPo, dPz=dPz, dPh=dPh, dPr=dPr, dEu=dEu, dE_p=dE_p,
+                ws=(K.C.c_void_p * 8)(*[ws.data_ptr() + o for o in offs]), ws_bytes=(K.C.c_size_t * 8)(*ws_bytes),
+                dWout=dWout.data_ptr(), dWz=dWz.data_ptr(), dWh=dWh.data_ptr(), dWr=dWr.data_ptr(),
+                dUr=dUr.data_ptr(), dbout=dbout.data_ptr(), dbz=dbz.data_ptr(), dbh=dbh.data_ptr(),
+                dbu=dbu.data_ptr(), dE=dE.data_ptr())
+            K.tree_encoder_backward(a, side)
+            out["keep"] = buffers  # alive until the call has been issued
+
+        _TreeGRU.backward(dh, sched, bs, NM, H, ld, dev, st, Pr, P.wid_m, P.mcsr_t, WzhT, WhhT, UrT, issue=issue)
+        # Scratch that the helper stream read or wrote goes back to the allocator of the stream it came from: the call
+        # has joined the helper into this stream, so whatever reuses the memory is ordered behind the helper's work.
         return dE, dWout, dbout, dWz, dbz, dWr, dUr, dbu, dWh, dbh, None, None, None, None, None
 
 
