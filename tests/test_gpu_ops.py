@@ -793,13 +793,25 @@ def test_graph_mpn_sweeps_reject_bad_arguments(K):
     assert K.lib.jtvae_graph_mpn_backward(C.byref(b), None) == -1
     b.n_bonds = -1
     assert K.lib.jtvae_graph_mpn_backward(C.byref(b), None) == -2
+    # jtvae_tree_encoder_backward: no block, no sweep block, inconsistent sizes, missing buffers
+    assert K.lib.jtvae_tree_encoder_backward(None, None, None) == -1
+    t = K.TreeEncBwd()
+    assert K.lib.jtvae_tree_encoder_backward(C.byref(t), None, None) == -1
+    sweep = K.TreeBwd()
+    t.sweep = C.pointer(sweep)
+    t.H, t.ld = 450, 448
+    assert K.lib.jtvae_tree_encoder_backward(C.byref(t), None, None) == -2
+    t.ld = 452
+    t.NM = t.B = t.NW = t.V = t.n_z = t.n_u = t.n_e = 4
+    assert K.lib.jtvae_tree_encoder_backward(C.byref(t), None, None) == -1
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M", [1, 77, 512])
 def test_small_tile_row_limit_picks_the_tiling_and_restores(K, M):
     """jtvae_set_small_tile_rows: a product of <= 512 rows takes the one-tile kernel by default and the 128 x 32
-    tiling with the limit at 0; both are fp32 fma chains, each within 2e-6 of sum |a w| of the fp64 product.  The setting is per thread, returns the previous value, and -1 restores the default."""
+    tiling with the limit at 0; both are fp32 fma chains, each within 2e-6 of sum |a w| of the fp64 product.  The
+    setting is per thread, returns the previous value, and -1 restores the default."""
     import threading
     import torch
     H, ld = 450, 452
