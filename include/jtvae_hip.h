@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define JTVAE_ABI_VERSION 18
+#define JTVAE_ABI_VERSION 19
 
 #define JTVAE_E_NULL (-1)     /* required pointer is NULL            */
 #define JTVAE_E_SHAPE (-2)    /* negative / inconsistent sizes       */
@@ -419,6 +419,31 @@ typedef struct jtvae_tree_bwd {
 } jtvae_tree_bwd_t;
 int jtvae_tree_gru_backward(const jtvae_tree_bwd_t* args, void* stream);
 
+/* JTNNEncoder.forward (fast_jtnn/jtnn_enc.py:20-42) around its level sweep as ONE host call: the embedding rows of
+ * the words used, the four per-word tables (W_z / W_h / outputNN input halves with their biases, W_r), iteration 0,
+ * the sweep (jtvae_tree_gru_forward on `sweep`, whose Pz / Pr / Ph / h / z / p / wid are the buffers used here), the
+ * root sums and the output layer on the roots.  `side` (or NULL): a second stream for the reset-gate and output
+ * tables, which the chain of levels reads only from level 1 on / after its last level; forked and joined inside.
+ * train != 0: iteration 0 stores z and p.  crowded != 0: the table products take the 128 x 32 tiling.  The same
+ * launches in the same order as issuing them one by one: bit-identical. */
+typedef struct jtvae_csr {
+  const int32_t* rowptr;
+  const int32_t* col;
+  int32_t n_rows;
+} jtvae_csr_t;
+typedef struct jtvae_tree_enc_fwd {
+  int32_t NM, B, NW, V, H, ld, crowded, train;
+  const float* E;                          /* embedding as a row buffer [V, ld] */
+  jtvae_csr_t word, root;                  /* word rows used (NW rows); messages into each root (B rows) */
+  const float *Wzx, *Whx, *Wox, *Wr, *Woh; /* weight blocks [H, ld] */
+  const float *bz, *bh, *bout;
+  const int32_t* wid_root;                 /* table row of each root's word */
+  const jtvae_tree_fwd_t* sweep;
+  float *Eu, *Po;                          /* [NW, ld]: word rows (kept for the backward pass), output table */
+  float *nsum, *tv;                        /* [B, ld]: root sums (kept), tree vectors */
+} jtvae_tree_enc_fwd_t;
+int jtvae_tree_encoder_forward(const jtvae_tree_enc_fwd_t* args, void* stream, void* side);
+
 /* Everything of JTNNEncoder's backward pass that surrounds the level sweep (autograd of fast_jtnn/jtnn_enc.py:27-41
  * and of the per-word table products that replace its W_z / W_r / W_h / outputNN input halves), as ONE host call:
  * the root stage (ReLU mask, W_out gradient, gradient into the messages that reach a root), the sweep
@@ -431,11 +456,6 @@ int jtvae_tree_gru_backward(const jtvae_tree_bwd_t* args, void* stream);
  * sums the pieces of a table row.  crowded != 0: products of <= 512 rows take the 128 x 32 tiling for the duration
  * of the call (jtvae_set_small_tile_rows(0)).  ws[i] / ws_bytes[i]: one jtvae_gemm_tn workspace per contraction
  * (0: W_out h-half, 1: o table, 2: z h-half, 3: h h-half, 4: U_r, 5: z table, 6: h table, 7: r table). */
-typedef struct jtvae_csr {
-  const int32_t* rowptr;
-  const int32_t* col;
-  int32_t n_rows;
-} jtvae_csr_t;
 typedef struct jtvae_tree_enc_bwd {
   int32_t NM, B, NW, V, H, ld, crowded;
   const float *Eu, *nsum, *tv;          /* kept by the forward pass: word rows used, root sums, root outputs */

@@ -1,6 +1,7 @@
-// JTNNEncoder's backward pass around the level sweep as ONE host call (see jtvae_tree_encoder_backward in the
-// header): ~35 launches that an interpreted host issues in ~0.35 ms and this routine in ~0.08 ms, which is what
-// bounds steps of a few hundred molecules and steps whose next batch is being prepared on the same interpreter.
+// JTNNEncoder's forward and backward pass around their level sweeps as ONE host call each (see
+// jtvae_tree_encoder_forward / _backward in the header): ~45 launches that an interpreted host issues in ~0.45 ms
+// and these routines in ~0.1 ms, which is what bounds steps of a few hundred molecules and steps whose next batch
+// is being prepared on the same interpreter.
 #include <cstdint>
 
 #include <hip/hip_runtime.h>
@@ -149,7 +150,71 @@ int run(const jtvae_tree_enc_bwd_t* a, void* stream, void* side) {
   return 0;
 }
 
+int run_forward(const jtvae_tree_enc_fwd_t* a, void* stream, void* side) {
+  const int32_t H = a->H, ld = a->ld, NW = a->NW;
+  const jtvae_tree_fwd_t* sw = a->sweep;
+  hipStream_t main_s = (hipStream_t)stream;
+  const bool forked = side != nullptr && side != stream;
+  hipStream_t side_s = forked ? (hipStream_t)side : main_s;
+  void* sd = forked ? side : stream;
+  // embedding rows of the words that occur in the batch                                    (jtnn_enc.py:27-28)
+  int rc = gather(a->Eu, a->E, a->V, a->word, H, ld, nullptr, 0, stream);
+  if (rc) return rc;
+  hipEvent_t r_done = nullptr, o_done = nullptr;
+  {
+    // With the graph encoder on another stream the table products start beside its first large products: they
+    // then take the tiling that finds room on a busy CU.
+    const int before = a->crowded ? jtvae_set_small_tile_rows(0) : -2;
+    // the reset-gate table is first read by level 1 of the sweep and the output table after it: with a helper
+    // stream they leave the chain of dependent launches that the sweep is
+    if (forked) rc = order_after(side_s, main_s);
+    jtvae_epilogue_t e = jtvae_epilogue_t();
+    e.zero_row = -1;
+    if (!rc) rc = jtvae_gemm_nt(a->Eu, ld, a->Wr, ld, const_cast<float*>(sw->Pr), ld, NW, H, H, &e, sd);
+    if (!rc && forked) rc = mark(side_s, &r_done);
+    e.bias = a->bout;
+    if (!rc) rc = jtvae_gemm_nt(a->Eu, ld, a->Wox, ld, a->Po, ld, NW, H, H, &e, sd);
+    if (!rc && forked) rc = mark(side_s, &o_done);
+    e.bias = a->bz;
+    if (!rc) rc = jtvae_gemm_nt(a->Eu, ld, a->Wzx, ld, const_cast<float*>(sw->Pz), ld, NW, H, H, &e, stream);
+    e.bias = a->bh;
+    if (!rc) rc = jtvae_gemm_nt(a->Eu, ld, a->Whx, ld, const_cast<float*>(sw->Ph), ld, NW, H, H, &e, stream);
+    if (before != -2) jtvae_set_small_tile_rows(before);
+    if (rc) return rc;
+  }
+  if (forked && (rc = after(main_s, r_done))) return rc;
+  // iteration 0 (h = 0), then every later level                                            (jtnn_enc.py:107-128)
+  rc = jtvae_gru_iter0(sw->Pz, sw->Ph, sw->wid, a->train ? sw->z : nullptr, a->train ? sw->p : nullptr, sw->h, a->NM,
+                       H, ld, sw->pad_row, stream);
+  if (rc) return rc;
+  rc = jtvae_tree_gru_forward(sw, stream);
+  if (rc) return rc;
+  if (forked && (rc = after(main_s, o_done))) return rc;
+  // output stage on the root nodes only                                                    (jtnn_enc.py:31-41)
+  rc = gather(a->nsum, sw->h, a->NM, a->root, H, ld, nullptr, 0, stream);
+  if (rc) return rc;
+  jtvae_epilogue_t e = jtvae_epilogue_t();
+  e.zero_row = -1;
+  e.add = a->Po;
+  e.ld_add = ld;
+  e.add_idx = a->wid_root;
+  e.act = JTVAE_ACT_RELU;
+  return jtvae_gemm_nt(a->nsum, ld, a->Woh, ld, a->tv, ld, a->B, H, H, &e, stream);
+}
+
 }  // namespace
+
+extern "C" int jtvae_tree_encoder_forward(const jtvae_tree_enc_fwd_t* a, void* stream, void* side) {
+  if (!a || !a->sweep) return JTVAE_E_NULL;
+  if (a->H <= 0 || a->ld < a->H || a->B <= 0 || a->NM <= 0 || a->NW <= 0 || a->V <= 0 || a->sweep->H != a->H ||
+      a->sweep->ld != a->ld)
+    return JTVAE_E_SHAPE;
+  if (!a->E || !a->Wzx || !a->Whx || !a->Wox || !a->Wr || !a->Woh || !a->wid_root || !a->Eu || !a->Po || !a->nsum ||
+      !a->tv || !a->sweep->Pz || !a->sweep->Pr || !a->sweep->Ph || !a->sweep->h || !a->sweep->wid ||
+      (a->train && (!a->sweep->z || !a->sweep->p)))
+    return JTVAE_E_NULL;
+  return run_forward(a, stream, side);
+}
 
 extern "C" int jtvae_tree_encoder_backward(const jtvae_tree_enc_bwd_t* a, void* stream, void* side) {
   if (!a || !a->sweep) return JTVAE_E_NULL;

@@ -26,7 +26,7 @@ LIB_PATH = os.environ.get("JTVAE_HIP_LIB") or os.path.join(_HERE, "libjtvae_hip.
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_BLEND, EPI_MUL_ACC = 0, 1, 2
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class Epilogue(C.Structure):
@@ -86,6 +86,14 @@ class TreeBwd(C.Structure):
 
 class Csr(C.Structure):  # jtvae_csr_t
     _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("n_rows", C.c_int32)]
+
+
+class TreeEncFwd(C.Structure):  # jtvae_tree_enc_fwd_t
+    _fields_ = ([(n, C.c_int32) for n in ("NM", "B", "NW", "V", "H", "ld", "crowded", "train")] +
+                [("E", C.c_void_p), ("word", Csr), ("root", Csr)] +
+                [(n, C.c_void_p) for n in ("Wzx", "Whx", "Wox", "Wr", "Woh", "bz", "bh", "bout", "wid_root")] +
+                [("sweep", C.POINTER(TreeFwd))] +
+                [(n, C.c_void_p) for n in ("Eu", "Po", "nsum", "tv")])
 
 
 class TreeEncBwd(C.Structure):  # jtvae_tree_enc_bwd_t
@@ -198,6 +206,7 @@ SIGNATURES = {
     "jtvae_tree_gru_forward": (C.c_int, [_vp, _vp]),
     "jtvae_tree_gru_backward": (C.c_int, [_vp, _vp]),
     "jtvae_tree_encoder_backward": (C.c_int, [_vp, _vp, _vp]),
+    "jtvae_tree_encoder_forward": (C.c_int, [_vp, _vp, _vp]),
     "jtvae_graph_mpn_forward": (C.c_int, [_vp, _vp]),
     "jtvae_graph_mpn_backward": (C.c_int, [_vp, _vp]),
     "jtvae_prep_group_by_key": (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
@@ -238,6 +247,9 @@ SIGNATURES = {
 
 
 HOST_PREFIXES = ("jtvae_prep_", "jtvae_tensorize_", "jtvae_select_")  # host-only routines, run for milliseconds
+# whole passes issued by one call (a dozen to ~70 launches, 0.05-0.3 ms of host time)
+LONG_CALLS = ("jtvae_tree_encoder_forward", "jtvae_tree_encoder_backward", "jtvae_graph_mpn_forward",
+              "jtvae_graph_mpn_backward", "jtvae_tree_gru_forward", "jtvae_tree_gru_backward")
 
 
 def _load():
@@ -246,17 +258,21 @@ def _load():
             "libjtvae_hip.so is not built (expected at %s); run `make -C jt-vae-tmcinvdes_amd/csrc` "
             "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % LIB_PATH
         )
-    # Two handles on the one library.  Kernel launches return in microseconds: they are called WITHOUT giving up
-    # the interpreter lock (PyDLL), because a stepping thread that drops it ~300 times per step has to win it
+    # Two handles on the one library.  Single kernel launches return in microseconds: they are called WITHOUT giving
+    # up the interpreter lock (PyDLL), because a stepping thread that drops it ~300 times per step has to win it
     # back each time from a prefetch thread that may be in the middle of Python code.  The host-side index
-    # routines (jtvae_prep_*) run for milliseconds and do release it (CDLL), so prefetch threads overlap them.
+    # routines (jtvae_prep_*) run for milliseconds and do release it (CDLL), so prefetch threads overlap them; so
+    # do the calls that issue a whole pass (LONG_CALLS): the ~0.6 ms per step the stepping thread spends inside
+    # them is when the preparation threads get their turns without stalling it (prefetched fresh-holder rate at
+    # 1024 molecules per step: 199 000-206 000 molecules/s against 164 000-192 000 with the lock held).
     host, launch = C.CDLL(LIB_PATH), C.PyDLL(LIB_PATH)
 
     class _Lib:
         pass
     lib = _Lib()
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(host if name.startswith(HOST_PREFIXES) else launch, name)  # AttributeError if not exported
+        releases = name.startswith(HOST_PREFIXES) or name in LONG_CALLS
+        fn = getattr(host if releases else launch, name)  # AttributeError if not exported
         fn.restype = res
         fn.argtypes = args
         setattr(lib, name, fn)
@@ -555,6 +571,11 @@ def tree_gru_forward(args):
 
 def tree_gru_backward(args):
     check(lib.jtvae_tree_gru_backward(C.byref(args), stream_ptr()), "tree_gru_backward")
+
+
+def tree_encoder_forward(args, side=None):
+    """``side``: raw handle of the helper stream, or None."""
+    check(lib.jtvae_tree_encoder_forward(C.byref(args), stream_ptr(), side), "tree_encoder_forward")
 
 
 def tree_encoder_backward(args, side=None):

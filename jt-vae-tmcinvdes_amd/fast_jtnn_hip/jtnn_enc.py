@@ -52,11 +52,14 @@ class _TreeGRU:
     """
 
     @staticmethod
-    def forward(sched, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur, bu, Whh, train, pad_row=0):
+    def forward(sched, NM, H, ld, dev, Pz, Pr, Ph, wid, mcsr, Wzh, Ur, bu, Whh, train, pad_row=0, issue=None):
+        """``issue(args)``: with the one-call schedule, called with the sweep's argument block INSTEAD of launching
+        iteration 0 and the sweep (the caller issues both inside a larger host call); see ``one_call``."""
         T = sched.T
         wid_p = wid.data_ptr()
         if T == 0:
             return K.rows(NM, ld, dev, zero=True), {}
+        one_call = issue is not None and _TreeGRU.one_call(sched)
         # With the compute-once schedule a message has ONE saved state, that of the iteration in which it
         # settled: all "slabs" alias one [NM, ld] buffer (slab stride 0) and later iterations overwrite the
         # provisional rows iteration 0 left there.  The other schedules keep one slab per iteration.
@@ -69,14 +72,16 @@ class _TreeGRU:
             stride = 0 if compact else NM * ld
             sf_p = sched.sf.data_ptr()
             st = dict(hs=hs, zs=zs, ps=ps, ss=ss, gs=gs, ts=ts, us=us, stride=stride)
-            K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, zs[0].data_ptr(), ps[0].data_ptr(),
-                        hs[0 if compact else 1].data_ptr(), NM, H, ld, pad_row)
+            if not one_call:
+                K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, zs[0].data_ptr(), ps[0].data_ptr(),
+                            hs[0 if compact else 1].data_ptr(), NM, H, ld, pad_row)
         else:
             # inference: one buffer each, updated in place (frozen rows simply keep their value)
             hs = torch.empty((1, NM, ld), dtype=torch.float32, device=dev)
             zs, ps, ss, gs, us = (torch.empty((1, NM, ld), dtype=torch.float32, device=dev) for _ in range(5))
             stride, sf_p, st = 0, None, {}
-            K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, None, None, hs[0].data_ptr(), NM, H, ld, pad_row)
+            if not one_call:
+                K.gru_iter0(Pz.data_ptr(), Ph.data_ptr(), wid_p, None, None, hs[0].data_ptr(), NM, H, ld, pad_row)
         if compact and T > 1 and K.sweeps_enabled():
             # all levels in one host call: the same launches in the same order as the loop below
             lists = sched.__dict__.get("_fwd_lists")
@@ -89,7 +94,10 @@ class _TreeGRU:
                           rowptr=mcsr.rowptr.data_ptr(), col=mcsr.col.data_ptr(), Wzh=Wzh.data_ptr(),
                           Whh=Whh.data_ptr(), Ur=Ur.data_ptr(), bu=None if bu is None else bu.data_ptr(), H=H, ld=ld,
                           pad_row=pad_row, n_levels=T - 1, f_rows=f_rows, f_n=f_n, u_rows=u_rows, u_n=u_n)
-            K.tree_gru_forward(a)
+            if one_call:
+                issue(a)
+            else:
+                K.tree_gru_forward(a)
             return hs[0], st
         for t in range(1, T):
             F, U = sched.F[t], sched.U[t]
@@ -116,6 +124,12 @@ class _TreeGRU:
         else:
             h = hs[0]
         return h, st
+
+    @staticmethod
+    def one_call(sched):
+        """The forward sweep goes out as one host call (compute-once schedule, more than one iteration, launches not
+        being timed one by one)."""
+        return sched.mode == "once" and sched.T > 1 and K.sweeps_enabled()
 
     @staticmethod
     def backward(dh, sched, bs, NM, H, ld, dev, st, Pr, wid, mcsr_t, WzhT, WhhT, UrT, pad_row=0, issue=None):
@@ -281,12 +295,51 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         # embedding rows of the words that occur in the batch            (jtnn_enc.py:27-28)
         E_p = as_row_buffer(E, H, ld)
         Eu = K.rows(NW, ld, dev)
-        K.csr_gather_sum(Eu.data_ptr(), E_p.data_ptr(), E.shape[0], None, P.word_csr.rowptr.data_ptr(),
-                         P.word_csr.col.data_ptr(), NW, H, ld, nnz=NW)
+        one_call = _TreeGRU.one_call(sched)
+        if not one_call:
+            K.csr_gather_sum(Eu.data_ptr(), E_p.data_ptr(), E.shape[0], None, P.word_csr.rowptr.data_ptr(),
+                             P.word_csr.col.data_ptr(), NW, H, ld, nnz=NW)
         Wzx, Wzh, Whx, Whh, Wox, Woh, Wr_p, Ur_p = pack_weights(
             [(Wz, 0, H, False), (Wz, H, H, False), (Wh, 0, H, False), (Wh, H, H, False), (Wout, 0, H, False),
              (Wout, H, H, False), (Wr, 0, H, False), (Ur_w, 0, H, False)])
         Pz, Pr, Ph, Po = (K.rows(NW, ld, dev) for _ in range(4))
+        if one_call:
+            # the whole pass in one host call (jtvae_tree_encoder_forward): the launches of the branch below in the
+            # same order, the helper stream forked and joined inside the call
+            nsum, tv = K.rows(B, ld, dev), K.rows(B, ld, dev)
+            side = side_streams[0].cuda_stream if len(side_streams) > 0 else None
+
+            def issue(sweep):
+                a = K.TreeEncFwd(NM=NM, B=B, NW=NW, V=E.shape[0], H=H, ld=ld, crowded=1 if crowded else 0,
+                                 train=1 if train else 0, E=E_p.data_ptr(), word=K.csr_arg(P.word_csr, NW),
+                                 root=K.csr_arg(P.rcsr, B), Wzx=Wzx.data_ptr(), Whx=Whx.data_ptr(), Wox=Wox.data_ptr(),
+                                 Wr=Wr_p.data_ptr(), Woh=Woh.data_ptr(), bz=bz.detach().data_ptr(),
+                                 bh=bh.detach().data_ptr(), bout=bout.detach().data_ptr(),
+                                 wid_root=P.wid_root.data_ptr(), sweep=K.C.pointer(sweep), Eu=Eu.data_ptr(),
+                                 Po=Po.data_ptr(), nsum=nsum.data_ptr(), tv=tv.data_ptr())
+                K.tree_encoder_forward(a, side)
+
+            h, st = _TreeGRU.forward(sched, NM, H, ld, dev, Pz, Pr, Ph, P.wid_m, P.mcsr, Wzh, Ur_p, bu.detach(), Whh,
+                                     train, issue=issue)
+        else:
+            h, st, nsum, tv = _JTNNEncoderFunction._forward_by_launch(
+                sched, P, NM, B, NW, H, ld, dev, Eu, (Pz, Pr, Ph, Po), (Wzx, Wzh, Whx, Whh, Wox, Woh, Wr_p, Ur_p),
+                (bz, bh, bout, bu), train, side_streams, crowded)
+        if train:
+            ctx.prep, ctx.depth, ctx.H, ctx.ld = P, depth, H, ld
+            ctx.st, ctx.sched = st, sched
+            ctx.keep = (Eu, Pr, nsum, tv, Wout, Wz, Wr, Ur_w, Wh)
+            ctx.vocab = E.shape[0]
+            ctx.side_streams = tuple(side_streams)
+            ctx.crowded = crowded
+        return dense_view(tv, H), dense_view(h, H)
+
+    @staticmethod
+    def _forward_by_launch(sched, P, NM, B, NW, H, ld, dev, Eu, tables, weights, biases, train, side_streams, crowded):
+        """The tables, the sweep and the output stage issued launch by launch (any schedule; the form that is timed)."""
+        Pz, Pr, Ph, Po = tables
+        Wzx, Wzh, Whx, Whh, Wox, Woh, Wr_p, Ur_p = weights
+        bz, bh, bout, bu = biases
         # the reset-gate table is first read by level 1 of the sweep and the output table after it: with a side
         # stream they leave the chain of dependent launches that the sweep is
         # With the graph encoder on another stream, the table products start beside its first large products:
@@ -310,14 +363,7 @@ class _JTNNEncoderFunction(torch.autograd.Function):
         tv = K.rows(B, ld, dev)
         K.gemm_nt(nsum.data_ptr(), ld, Woh.data_ptr(), ld, tv.data_ptr(), ld, B, H, H, add=Po.data_ptr(),
                   ld_add=ld, add_idx=P.wid_root.data_ptr(), act=K.ACT_RELU)
-        if train:
-            ctx.prep, ctx.depth, ctx.H, ctx.ld = P, depth, H, ld
-            ctx.st, ctx.sched = st, sched
-            ctx.keep = (Eu, Pr, nsum, tv, Wout, Wz, Wr, Ur_w, Wh)
-            ctx.vocab = E.shape[0]
-            ctx.side_streams = tuple(side_streams)
-            ctx.crowded = crowded
-        return dense_view(tv, H), dense_view(h, H)
+        return h, st, nsum, tv
 
     @staticmethod
     def backward(ctx, dtv, dmess):

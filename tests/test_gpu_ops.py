@@ -804,6 +804,16 @@ def test_graph_mpn_sweeps_reject_bad_arguments(K):
     t.ld = 452
     t.NM = t.B = t.NW = t.V = t.n_z = t.n_u = t.n_e = 4
     assert K.lib.jtvae_tree_encoder_backward(C.byref(t), None, None) == -1
+    assert K.lib.jtvae_tree_encoder_forward(None, None, None) == -1
+    f = K.TreeEncFwd()
+    assert K.lib.jtvae_tree_encoder_forward(C.byref(f), None, None) == -1  # no sweep block
+    fs = K.TreeFwd()
+    f.sweep = C.pointer(fs)
+    f.NM = f.B = f.NW = f.V = 4
+    f.H, f.ld = 450, 452
+    assert K.lib.jtvae_tree_encoder_forward(C.byref(f), None, None) == -2  # the sweep block disagrees on H / ld
+    fs.H, fs.ld = 450, 452
+    assert K.lib.jtvae_tree_encoder_forward(C.byref(f), None, None) == -1  # no buffers
 
 
 @pytest.mark.gpu
