@@ -93,3 +93,22 @@ def test_state_dict_keys_match_reference_layout():
     }
     for k, shp in want.items():
         assert sd.get(k) == shp, (k, sd.get(k))
+
+
+def test_which_calls_give_up_the_interpreter_lock():
+    """Single launches are bound through the handle that keeps the interpreter lock (microseconds each); the host-side
+    preparation routines and the calls that issue a whole pass through the one that releases it, so that background
+    preparation threads run while the stepping thread is inside them."""
+    from fast_jtnn_hip import _capi as K
+
+    keeps = ctypes.PyDLL(K.LIB_PATH).jtvae_abi_version._flags_
+    releases = ctypes.CDLL(K.LIB_PATH).jtvae_abi_version._flags_
+    assert keeps != releases
+    for name in K.SIGNATURES:
+        want = releases if name.startswith(K.HOST_PREFIXES) or name in K.LONG_CALLS else keeps
+        assert getattr(K.lib, name)._flags_ == want, name
+    assert set(K.LONG_CALLS) <= set(K.SIGNATURES)
+    for name in ("jtvae_gemm_nt", "jtvae_csr_gather_sum", "jtvae_gru_update"):
+        assert getattr(K.lib, name)._flags_ == keeps
+    for name in ("jtvae_tree_encoder_backward", "jtvae_graph_mpn_forward", "jtvae_prep_transpose_csr"):
+        assert getattr(K.lib, name)._flags_ == releases

@@ -505,3 +505,24 @@ def test_linear_matches_nn_linear_in_fp64(n, kin, out_f):
     for k in want:
         scale = float(want[k].abs().max()) + 1e-30
         assert float((got[k] - want[k]).abs().max()) < 3e-5 * scale, k
+
+
+def test_small_batches_stay_on_one_stream():
+    """overlap_streams is a request: below overlap_min_messages tree messages the encoders run on the caller's stream
+    (the forks and joins cost more host time than a step of that size gains), and the results are those of the
+    two-stream step to rounding (the short products' tiling follows the stream layout)."""
+    g, x_batch = _seeded_training_problem(79, 16, 20.0)
+    hip = make_hip_model(g, "cuda")
+    hip.overlap_streams = True
+    _, jt, mp, _ = x_batch()
+    assert int(jt[3].shape[0]) < hip.overlap_min_messages
+    with torch.no_grad():
+        a = hip.encode_latent(jt, mp)
+    assert hip.jtnn.side_streams == ()  # one stream: no helper stream was handed to the tree encoder
+    hip.overlap_min_messages = 0
+    with torch.no_grad():
+        b = hip.encode_latent(jt, mp)
+    assert len(hip.jtnn.side_streams) == 1
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert float((x - y).abs().max()) < 1e-5 * float(y.abs().max())
