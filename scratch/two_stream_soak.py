@@ -11,6 +11,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 dev = torch.device("cuda", 0)
 model, jt, mp, xb, stats = bench.build_problem(1234, B, 385, dev, "train")
+model.jtnn.crowded = True  # one tiling of the short products for both stream layouts: the comparison is bit for bit
+model.overlap_min_messages = 0
 batches = [(jt, mp)]
 for i in range(3):
     trees = synthetic.make_batch(500 + i, B, vocab_size=385, mean_atoms=40.0)
