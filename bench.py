@@ -382,7 +382,7 @@ def main():
                          "under their own metric names (see the module docstring)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the tree encoder and the graph encoder back to back on one stream instead of on two "
-                         "overlapping ones (results are bit-identical either way)")
+                         "overlapping ones (results agree to rounding; bit for bit with JTNNEncoder.crowded pinned)")
     ap.add_argument("--backend", default="nccl", help="collective backend; gloo lets several ranks rehearse the "
                                                       "N > 1 path on one GPU")
     args = ap.parse_args()

@@ -182,7 +182,9 @@ class JTNNVAE(nn.Module):
     # iterations of the tree GRU are short launches that leave most of the GPU idle: on a GPU the
     # two can run on two side streams, so that the graph encoder's large GEMMs fill those gaps (autograd
     # replays each backward on the stream of its forward, so the backward passes overlap as well).
-    # Results are bit-identical to the one-stream order.  Off by default: the reference issues
+    # The launches and their data are those of the one-stream order; only the tiling of the tree encoder's short
+    # products follows the stream layout (JTNNEncoder.crowded), so results agree to rounding by default and bit for bit
+    # with that choice pinned.  Off by default: the reference issues
     # everything on one stream, and per-kernel timings are only meaningful without co-running kernels.
     overlap_streams = False
     # Batches below this many tree messages (about 150 molecules) stay on one stream even with overlap_streams set:

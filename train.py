@@ -129,7 +129,7 @@ def main(argv=None):
         model.load_state_dict(torch.load(os.path.join(args.save_dir, "model.epoch-%d" % args.load_epoch),
                                          map_location="cpu", weights_only=True))
     model = model.to(device)
-    model.overlap_streams = device.type == "cuda"  # tree and graph encoder on two streams: same bits, shorter step
+    model.overlap_streams = device.type == "cuda"  # tree and graph encoder on two streams: same results to rounding, shorter step
     if rank == 0:
         print("Model #Params: %dK" % (sum(x.nelement() for x in model.parameters()) / 1000,))
     sched = trainer.Schedule(lr=args.lr, clip_norm=args.clip_norm, beta=args.beta, step_beta=args.step_beta,
