@@ -424,7 +424,8 @@ int jtvae_tree_gru_backward(const jtvae_tree_bwd_t* args, void* stream);
  * the sweep (jtvae_tree_gru_forward on `sweep`, whose Pz / Pr / Ph / h / z / p / wid are the buffers used here), the
  * root sums and the output layer on the roots.  `side` (or NULL): a second stream for the reset-gate and output
  * tables, which the chain of levels reads only from level 1 on / after its last level; forked and joined inside.
- * train != 0: iteration 0 stores z and p.  crowded != 0: the table products take the 128 x 32 tiling.  The same
+ * train != 0: iteration 0 stores z and p.  crowded bit 0: the table products take the 128 x 32 tiling
+ * (jtvae_set_small_tile_rows(0) for their duration), bit 1: so do the short levels of the sweep.  The same
  * launches in the same order as issuing them one by one: bit-identical. */
 typedef struct jtvae_csr {
   const int32_t* rowptr;

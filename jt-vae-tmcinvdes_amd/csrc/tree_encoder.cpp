@@ -164,7 +164,7 @@ int run_forward(const jtvae_tree_enc_fwd_t* a, void* stream, void* side) {
   {
     // With the graph encoder on another stream the table products start beside its first large products: they
     // then take the tiling that finds room on a busy CU.
-    const int before = a->crowded ? jtvae_set_small_tile_rows(0) : -2;
+    const int before = (a->crowded & 1) ? jtvae_set_small_tile_rows(0) : -2;
     // the reset-gate table is first read by level 1 of the sweep and the output table after it: with a helper
     // stream they leave the chain of dependent launches that the sweep is
     if (forked) rc = order_after(side_s, main_s);
@@ -187,7 +187,12 @@ int run_forward(const jtvae_tree_enc_fwd_t* a, void* stream, void* side) {
   rc = jtvae_gru_iter0(sw->Pz, sw->Ph, sw->wid, a->train ? sw->z : nullptr, a->train ? sw->p : nullptr, sw->h, a->NM,
                        H, ld, sw->pad_row, stream);
   if (rc) return rc;
-  rc = jtvae_tree_gru_forward(sw, stream);
+  {
+    // in a large batch the graph encoder is still running when the sweep reaches its short levels
+    const int before = (a->crowded & 2) ? jtvae_set_small_tile_rows(0) : -2;
+    rc = jtvae_tree_gru_forward(sw, stream);
+    if (before != -2) jtvae_set_small_tile_rows(before);
+  }
   if (rc) return rc;
   if (forked && (rc = after(main_s, o_done))) return rc;
   // output stage on the root nodes only                                                    (jtnn_enc.py:31-41)

@@ -585,15 +585,22 @@ def test_one_deep_tree_in_a_batch_keeps_the_batch_on_the_compute_once_schedule()
         assert fro_err(out["once"][2][n], q.grad.numpy()) < RTOL, n
 
 
-def test_one_call_level_sweeps_are_bitwise_the_launch_by_launch_form():
-    """jtvae_tree_gru_forward / _backward issue the launches of the level loop in the same order, and
-    jtvae_graph_mpn_forward / _backward those of the graph encoder and the candidate encoder: outputs and every
-    gradient are bit-identical to the launch-by-launch form (which is what runs while launches are being timed),
-    with the gradient reaching all messages (through JTMPN) and with it reaching the roots only."""
+@pytest.mark.parametrize("crowded,sweep_too", [(None, False), (True, False), (True, True)])
+def test_one_call_level_sweeps_are_bitwise_the_launch_by_launch_form(crowded, sweep_too, monkeypatch):
+    """jtvae_tree_encoder_forward / _backward (with jtvae_tree_gru_forward / _backward inside) issue the launches of
+    the tree encoder in the same order as the launch-by-launch form, and jtvae_graph_mpn_forward / _backward those of
+    the graph encoder and the candidate encoder: outputs and every gradient are bit-identical to the launch-by-launch
+    form (which is what runs while launches are being timed), with the gradient reaching all messages (through JTMPN)
+    and with it reaching the roots only - also with the short products on the tiling for crowded CUs, tables and
+    backward sweep only or the forward sweep as well."""
     from fast_jtnn_hip import _capi as K
+    from fast_jtnn_hip import jtnn_enc
 
     g = Golden(CASES[2])
     m = make_hip_model(g, "cuda")
+    m.jtnn.crowded = crowded
+    if sweep_too:
+        monkeypatch.setattr(jtnn_enc, "CROWDED_SWEEP_MIN_MESSAGES", 0)
 
     def run(with_cands):
         m.zero_grad(set_to_none=True)
