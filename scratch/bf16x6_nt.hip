@@ -909,9 +909,9 @@ int main(int argc, char** argv) {
     return (float)(((double)hi + (double)(s >> 8) / 16777216.0) / 8388608.0 - 1.0);  // full 24-bit significands
   };
   for (int i = 0; i < M; ++i)
-    for (int k = 0; k < K; ++k) hA[(size_t)i * ld + k] = rnd() * (1.f + (i % 7));
+    for (int k = 0; k < K; ++k) hA[(size_t)i * ld + k] = getenv("ZERO_A") ? 0.f : rnd() * (1.f + (i % 7));
   for (int n = 0; n < N; ++n)
-    for (int k = 0; k < K; ++k) hW[(size_t)n * ld + k] = rnd() * 0.05f;
+    for (int k = 0; k < K; ++k) hW[(size_t)n * ld + k] = getenv("ZERO_W") ? 0.f : rnd() * 0.05f;
   float *dA, *dW, *dC;
   CK(hipMalloc(&dA, hA.size() * 4));
   CK(hipMalloc(&dW, hW.size() * 4));
