@@ -11,7 +11,9 @@
  * Conventions
  *  - every pointer is DEVICE memory unless the parameter is documented "host";
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream);
- *    every call only enqueues work, none synchronises or allocates;
+ *    every call only enqueues work, none synchronises or allocates device memory
+ *    (jtvae_tree_encoder_forward / _backward create a small ring of events per host
+ *    thread and device the first time they fork their helper stream);
  *  - return value: 0 = ok, negative = argument rejected before any launch
  *    (JTVAE_E_*), positive = hipError_t from the launch;
  *  - "row buffers" hold one feature row per graph element, fp32, row-major with
